@@ -1,0 +1,227 @@
+"""Generate tests/golden/*.npz by running the reference's own class bodies on CPU.
+
+Run in the build container only:  python tools/make_goldens.py
+Reads /root/reference at run time (tools/ref_loader.py); commits only numeric outputs.
+Weights/inputs are regenerated in the tests from numpy seeds (oracle/params.py), so fixtures hold
+outputs, losses, gradients (full for small tensors, else norm + strided sample) and buffers.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_loader as R                     # noqa: E402
+from oracle import params as P             # noqa: E402
+from oracle.gwnet_ref import asym_adj      # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+torch.set_num_threads(8)
+
+
+def rand(seed, shape):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+
+
+def grad_summary(module, max_full=4096):
+    out = {}
+    none = []
+    for k, prm in module.named_parameters():
+        if prm.grad is None:
+            none.append(k)
+            continue
+        g = prm.grad.detach().numpy()
+        out['gnorm/' + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        if g.size <= max_full:
+            out['grad/' + k] = g
+        else:
+            out['gsample/' + k] = g.reshape(-1)[::max(1, g.size // 2048)][:2048].copy()
+    out['none_grads'] = np.array(none)
+    return out
+
+
+def buffers(module):
+    return {'buf/' + k: v.detach().numpy().copy() for k, v in module.state_dict().items()
+            if 'running_' in k or 'num_batches' in k}
+
+
+def schema_of(module):
+    return [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+
+
+def gwnet_case(name, *, B, N, T, in_dim, out_dim, K, static_supports, generic, seed, horizon=1,
+               dropout=0.0, train_steps=1):
+    sup_t = [torch.from_numpy(s) for s in static_supports]
+    ns = R.load_gwnet(generic, sup_t, n_counties=N)
+    g = ns['gwnet']('cpu', num_nodes=N, dropout=dropout, supports=sup_t, in_dim=in_dim,
+                    out_dim=out_dim, horizon=horizon, kernel_size=K)
+    schema = P.gwnet_schema(num_nodes=N, supports_len=len(sup_t) + 1, in_dim=in_dim,
+                            out_dim=out_dim, kernel_size=K)
+    assert schema_of(g) == [(k, tuple(v)) for k, v in schema.items()], 'schema mismatch'
+    P.load_into(g, P.seeded_values(schema, seed))
+    g.train()
+    if generic:
+        x = rand(seed + 1, (B, in_dim, N, T))
+    else:
+        x = rand(seed + 1, (N, horizon, in_dim))
+    x.requires_grad_(True)
+    y = g(x)
+    tgt = rand(seed + 2, tuple(y.shape))
+    loss = F.mse_loss(y, tgt)
+    loss.backward()
+    d = dict(y=y.detach().numpy(), loss=np.float64(loss.item()), dx=x.grad.numpy(),
+             seed=np.int64(seed), receptive_field=np.int64(g.receptive_field))
+    d.update(grad_summary(g))
+    d.update(buffers(g))
+    # eval-mode output with the updated running stats
+    g.eval()
+    with torch.no_grad():
+        d['y_eval'] = g(x.detach()).numpy()
+    # adaptive adjacency
+    with torch.no_grad():
+        d['adp'] = F.softmax(F.relu(torch.mm(g.nodevec1, g.nodevec2)), dim=1).numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'loss', loss.item(), 'y', tuple(y.shape), 'none grads', len(d['none_grads']))
+
+
+def unet_blocks_case(seed=300):
+    ns_g = R.load_gwnet(False, [torch.eye(67)])
+    ns = R.load_unet(ns_g['gwnet'])
+    d = {}
+    # DoubleConv / Down / Up / OutConv at tiny shapes (unet.py:40-92)
+    for nm, ctor, shapes in (
+            ('double_conv', lambda: ns['DoubleConv'](3, 8), [(2, 3, 12, 10)]),
+            ('down', lambda: ns['Down'](4, 8), [(3, 4, 16, 16)]),
+            ('up', lambda: ns['Up'](16, 8), [(2, 16, 5, 6), (2, 8, 11, 13)]),
+            ('outc', lambda: ns['OutConv'](4, 2), [(2, 4, 9, 7)])):
+        torch.manual_seed(0)
+        m = ctor()
+        vals = P.seeded_values({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+        P.load_into(m, vals)
+        m.train()
+        ins = [rand(seed + 10 + i, s).requires_grad_(True) for i, s in enumerate(shapes)]
+        y = m(*ins)
+        tgt = rand(seed + 20, tuple(y.shape))
+        loss = F.mse_loss(y, tgt)
+        loss.backward()
+        d[nm + '/y'] = y.detach().numpy()
+        d[nm + '/loss'] = np.float64(loss.item())
+        for i, t in enumerate(ins):
+            d[f'{nm}/dx{i}'] = t.grad.numpy()
+        for k, prm in m.named_parameters():
+            d[f'{nm}/grad/{k}'] = prm.grad.numpy()
+        for k, v in buffers(m).items():
+            d[f'{nm}/{k}'] = v
+        d[nm + '/keys'] = np.array([k for k in m.state_dict().keys()])
+    np.savez_compressed(os.path.join(OUT, 'unet_blocks.npz'), **d)
+    print('unet_blocks done')
+
+
+def modified_unet_case(name, B, H, seed):
+    sup = [torch.eye(67)]
+    ns_g = R.load_gwnet(False, sup)
+    ns = R.load_unet(ns_g['gwnet'])
+    m = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=1, output_channels=1)
+    schema = P.unet_schema()
+    assert schema_of(m) == [(k, tuple(v)) for k, v in schema.items()], 'unet schema mismatch'
+    P.load_into(m, P.seeded_values(schema, seed))
+    m.st_gnn.dropout = 0.0
+    for g in m.st_gnn.gconv:
+        g.dropout = 0.0
+    m.encoder.dropout1.p = 0.0
+    m.decoder.dropout1.p = 0.0
+    m.train()
+    x = rand(seed + 1, (B, 67, H, 1, 128, 128))
+    tdim = rand(seed + 3, (B, 67, H, 64))
+    y = m(x, tdim)
+    tgt = rand(seed + 2, tuple(y.shape))
+    loss = F.mse_loss(y, tgt)
+    loss.backward()
+    yn = y.detach().numpy()
+    d = dict(loss=np.float64(loss.item()), y_shape=np.array(yn.shape),
+             y_sample=yn.reshape(-1)[::997].copy(), y_mean=np.float64(yn.mean()),
+             y_sqsum=np.float64((yn.astype(np.float64) ** 2).sum()),
+             y_first=yn[0, 0, 0, 0].copy(), y_last=yn[-1, -1, -1, 0].copy(),
+             seed=np.int64(seed))
+    d.update(grad_summary(m, max_full=1100))
+    d.update(buffers(m))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'loss', loss.item())
+
+
+def csr_case():
+    import pandas as pd
+    import scipy.sparse as sp
+    A = pd.read_csv(f'{R.REF}/data/graph/adj_mx_fl.csv', index_col=0).values.astype(np.float32)
+    c = sp.csr_matrix(A)
+    ct = sp.csr_matrix(A.T)
+    asym = R.load_asym_adj()
+    d = dict(adj=A, rowptr=c.indptr.astype(np.int32), colidx=c.indices.astype(np.int32),
+             vals=c.data.astype(np.float32), t_rowptr=ct.indptr.astype(np.int32),
+             t_colidx=ct.indices.astype(np.int32), t_vals=ct.data.astype(np.float32),
+             asym=np.asarray(asym(A)), asym_t=np.asarray(asym(A.T)))
+    # reference load_adj('doubletransition') output (graph_wavenet.py:13-32) == [I_N]
+    src_ns = {}
+    import ast
+    tree = ast.parse(open(f'{R.REF}/models/graph_wavenet.py').read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'load_adj']
+    exec(compile(ast.Module(body=fn, type_ignores=[]), 'ref_load_adj', 'exec'),
+         dict(pd=pd, np=np), src_ns)
+    _, _, adjs = src_ns['load_adj'](f'{R.REF}/data/graph/adj_mx_fl.csv', 'doubletransition')
+    d['load_adj0'] = adjs[0]
+    # asym_adj on the synthetic k-NN graph used by the bench (N=20 case)
+    Ak = P.knn_graph(20)
+    d['knn20'] = Ak
+    d['knn20_asym'] = np.asarray(asym(Ak))
+    np.savez_compressed(os.path.join(OUT, 'adjacency.npz'), **d)
+    print('adjacency nnz', c.nnz)
+
+
+def date2vec_case(seed=500):
+    d2v = R.load_date2vec()
+    m = d2v.Date2Vec(k=64)
+    vals = P.seeded_values({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+    P.load_into(m, vals)
+    m.eval()
+    x = torch.tensor([[0, 0, 0, 2018, 10, 10], [0, 0, 0, 2022, 9, 26], [0, 0, 0, 2023, 8, 30]],
+                     dtype=torch.float32)
+    with torch.no_grad():
+        y = m.encode(x)
+    np.savez_compressed(os.path.join(OUT, 'date2vec.npz'), x=x.numpy(), y=y.numpy(),
+                        seed=np.int64(seed), keys=np.array(list(m.state_dict().keys())))
+    print('date2vec', tuple(y.shape))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['gwnet', 'blocks', 'csr', 'd2v', 'unet']
+    if 'gwnet' in which:
+        # R: reference default, 3-D input through the :189/:255 views, K=1, supports=[I]
+        gwnet_case('gwnet_R', B=1, N=67, T=7, in_dim=320, out_dim=256, K=1,
+                   static_supports=[np.eye(67, dtype=np.float32)], generic=False, seed=100,
+                   horizon=7)
+        # C1: BASELINE config 1 (N=20, T=12, Cin=2, B=4, K=2, two static supports + adaptive)
+        A20 = P.knn_graph(20)
+        gwnet_case('gwnet_C1', B=4, N=20, T=12, in_dim=2, out_dim=12, K=2,
+                   static_supports=[asym_adj(A20), asym_adj(A20.T)], generic=True, seed=200)
+        # C1b: K=2 with T shorter than the receptive field (left pad path) and odd N
+        A37 = P.knn_graph(37, seed=3)
+        gwnet_case('gwnet_C1b', B=3, N=37, T=5, in_dim=5, out_dim=3, K=2,
+                   static_supports=[asym_adj(A37)], generic=True, seed=210)
+        # C1c: T longer than the receptive field (T_final > 1)
+        gwnet_case('gwnet_C1c', B=2, N=20, T=16, in_dim=4, out_dim=6, K=2,
+                   static_supports=[asym_adj(A20), asym_adj(A20.T)], generic=True, seed=220)
+    if 'blocks' in which:
+        unet_blocks_case()
+    if 'csr' in which:
+        csr_case()
+    if 'd2v' in which:
+        date2vec_case()
+    if 'unet' in which:
+        modified_unet_case('modified_unet_B2H2', B=2, H=2, seed=400)
