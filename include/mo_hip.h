@@ -1,0 +1,129 @@
+/* mo_hip.h -- C-ABI of the MI355X-native Graph-WaveNet + UNet training hot path.
+ *
+ * The reference (aaparcedo/multimodal_outage) is pure Python/PyTorch and has no native layer; every
+ * entry point below replaces the stock-PyTorch op sequence of the cited reference lines.  Binding:
+ * ctypes (multimodal_outage_amd/_lib.py); see INTEGRATION.md.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers to fp32 data (int32 for CSR indices) owned by the caller
+ *    (torch allocates every buffer, including workspaces); the library allocates nothing.
+ *  - All work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no device sync.
+ *  - Return 0 on success, a negative MO_E* code otherwise; nothing is thrown across the ABI.
+ *  - "nbtc" = the library's internal channels-last activation layout: a (B,C,N,T) tensor is stored as
+ *    rows p = (n*B + b)*T + t of C contiguous channels (node-major so the node-axis products are
+ *    plain row operations on [N][B*T*C]).
+ */
+#ifndef MO_HIP_H
+#define MO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MO_OK 0
+#define MO_EINVAL (-1)
+#define MO_ELAUNCH (-2)
+#define MO_EUNSUPPORTED (-3)
+#define MO_ECOMM (-4)
+
+const char* mo_strerror(int code);
+int mo_version(void);
+
+/* ---- layout: graph_wavenet.py:189/:255 boundary, (B,C,N,T) <-> nbtc -------------------------- */
+int mo_nchw_to_nbtc(const float* x, float* y, int B, int C, int N, int T, void* stream);
+int mo_nbtc_to_nchw(const float* y, float* x, int B, int C, int N, int T, void* stream);
+
+/* ---- 1x1 conv / Linear (start_conv :117-119,196; skip_convs :164-166,230-236; end_conv_1/2 :174-183,
+ *      252-254; residual_convs :159-161,245; Encoder/Decoder fc unet.py:132-136,156-160) -----------
+ * out[p][co] = act( sum_ci f(in[map(p)][ci]) * W[co][ci] + b[co] )  (+ out[p][co] if beta)
+ * rows of `in` are mapped per group: p=(g,t), t in [0,To) -> in row g*Ti + t + off (zero if outside
+ * [0,Ti)); To==0 means identity.  in_relu applies ReLU to the input on load (head: relu(skip)). */
+int mo_conv1x1_fwd(const float* in, int Ci, int To, int Ti, int off, int in_relu,
+                   const float* W, const float* b, int Co, float* out, long P_out, int out_relu,
+                   int beta, void* stream);
+/* din[omap(p)][ci] (+)= sum_co dout[p][co]*W[co][ci], optionally masked by (mask[p'][ci] > 0) where p'
+ * indexes the rows of din (ReLU backward); output rows mapped as above (rows without image skipped). */
+int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const float* W, int Ci, float* din,
+                        int oTo, int oTi, int ooff, const float* mask, int beta, void* stream);
+/* dW[co][ci] = sum_p dout[p][co]*f(in[map(p)][ci]);  db[co] = sum_p dout[p][co] (db may be null).
+ * ws: workspace of mo_wgrad_ws_floats(Co, Ci, P) floats. */
+long mo_wgrad_ws_floats(int M, int N, long P);
+int mo_conv1x1_bwd_weight(const float* dout, int Co, long P, const float* in, int Ci, int To, int Ti,
+                          int off, int in_relu, float* dW, float* db, float* ws, void* stream);
+
+/* ---- adaptive adjacency (graph_wavenet.py:202): adp = softmax(relu(E1 @ E2), dim=1); also adp^T - */
+int mo_adp_fwd(const float* E1, const float* E2, int N, int R, float* adp, float* adpT, void* stream);
+/* given dAdp (N,N) (overwritten with dz), produce dE1 (N,R), dE2 (R,N). ws: N*R*mo_adp_bwd_splits floats */
+int mo_adp_bwd(const float* E1, const float* E2, const float* adp, float* dA, int N, int R,
+               float* dE1, float* dE2, float* ws, long ws_floats, void* stream);
+
+/* ---- gated TCN (graph_wavenet.py:150-156,222-226): g = tanh(conv_f(u)) * sigmoid(conv_g(u)),
+ *      kernel (1,K), dilation d, u = h_prev*scale+shift (BatchNorm of the previous layer folded into
+ *      the load; scale/shift may be null).  Weights are the reference tensors (32,32,1,K). --------- */
+int mo_tcn_pack_weights(const float* Wf, const float* Wg, int K, float* Wp, void* stream);
+int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
+               const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
+               void* stream);
+/* backward: recomputes the pre-activations; dpre (ws, G*Tout*64 floats) ; du[G*Tin][32] = conv^T(dpre)
+ * (+ dres[(g,t-(Tin-Tout))] when dres != null: the residual path of graph_wavenet.py:247);
+ * dWf,dWg (32,32,1,K), dbf,dbg (32). ws2: mo_wgrad_ws_floats(64, 32*K, G*Tout) floats. */
+int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
+               const float* bf, const float* bg, int K, int dil, long G, int Tin, const float* dg,
+               const float* dres, float* du, float* dWf, float* dWg, float* dbf, float* dbg,
+               float* dpre_ws, float* ws2, void* stream);
+
+/* ---- diffusion graph convolution, node-axis products (nconv, graph_wavenet.py:64-66) -----------
+ * Y[w][:] (+)= sum_e vals[e] * X[colidx[e]][:],  e in [rowptr[w], rowptr[w+1]);  rows of J floats.
+ * forward uses the CSR of A^T (out[w] = sum_v A[v,w] x[v]); backward the CSR of A. */
+int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const float* vals, int n_rows,
+                const float* X, float* Y, long J, int beta, void* stream);
+/* dense support: Y[N][J] (+)= A_km^T @ X with A_km (N,N) row-major indexed [k][m]
+ * (forward: A_km = adp; backward-data: A_km = adp^T). */
+int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, long J, int beta, void* stream);
+/* dA[v][w] (+)= sum_j X[v][j] * dY[w][j]   (gradient of the adaptive adjacency) */
+int mo_adj_grad(const float* X, const float* dY, int N, long J, float* dA, int beta, void* stream);
+
+/* ---- gcn mlp + dropout + residual + BatchNorm statistics (graph_wavenet.py:95-97,247,250) -------
+ * h[p][:] = drop(W @ cat[srcs[0..ns)][p] + b) + (res[(g,t+Tin-Tout)]*rscale+rshift); per-block BN
+ * partial sums go to `partial` (mo_mlp_partial_floats(P) floats). ns = 2S+1 sources of [P][32].
+ * W is the reference mlp weight (32, ns*32, 1, 1). drop_thresh = p*2^32 (0: off). */
+long mo_mlp_partial_floats(long P);
+int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, const float* b, long G, int Tout,
+                   int Tin, const float* res, const float* rscale, const float* rshift,
+                   uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* h,
+                   float* partial, void* stream);
+/* BatchNorm2d finalize (training: batch stats + running-stat update, momentum 0.1 semantics of
+ * nn.BatchNorm2d; eval: running stats).  Outputs scale/shift (the folded affine), mean, rstd. */
+int mo_bn_finalize(const float* partial, long nblk, long count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, int training,
+                   float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* BatchNorm backward: dh = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); dgamma, dbeta.
+ * ws: mo_mlp_partial_floats(P) floats. */
+int mo_bn_bwd(const float* dy, const float* h, long P, const float* gamma, const float* mean,
+              const float* rstd, float* dh, float* dgamma, float* dbeta, float* ws, void* stream);
+/* mlp backward: dsrcs[s][p][:] = (dh*dropmask)[p][:] @ W[:, s*32:(s+1)*32];  dW, db.
+ * ws: mo_wgrad_ws_floats(32, ns*32, P) floats. */
+int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrcs, int ns,
+                   const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
+                   float* dW, float* db, float* ws, void* stream);
+
+/* ---- loss + metrics (lit.py:33-38): sums[0..3] = {sum d^2, sum |d|, sum |d|/max(|y|,1.17e-6), n};
+ *      grad (optional) = 2*d/n.  ws: mo_metrics_ws_floats(n). --------------------------------------- */
+long mo_metrics_ws_floats(long n);
+int mo_mse_metrics(const float* yhat, const float* y, long n, float* sums, float* grad, float* ws,
+                   void* stream);
+
+/* ---- Date2Vec.encode (date2vec.py:49-53): out[i] = cat[fc1(x[i]), sin(fc2(x[i]))], 6 -> k1+k2 ---- */
+int mo_date2vec_encode(const float* x, long n, const float* W1, const float* b1, int k1,
+                       const float* W2, const float* b2, int k2, float* out, void* stream);
+
+/* ---- utility ------------------------------------------------------------------------------------ */
+int mo_colsum(const float* X, long P, int C, float* out, float* ws, void* stream);
+long mo_colsum_ws_floats(long P, int C);
+int mo_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                 float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

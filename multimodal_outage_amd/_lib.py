@@ -1,0 +1,93 @@
+"""ctypes binding of the C-ABI declared in include/mo_hip.h.
+
+The product has NO CPU fallback: if libmo_hip.so is missing the import of any op raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmo_hip.so')
+
+_lib = None
+
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes); mirrors include/mo_hip.h one to one
+SIGNATURES = {
+    'mo_strerror': (C.c_char_p, [i32]),
+    'mo_version': (i32, []),
+    'mo_nchw_to_nbtc': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'mo_nbtc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'mo_conv1x1_fwd': (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, i32, vp]),
+    'mo_conv1x1_bwd_data': (i32, [vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, vp]),
+    'mo_wgrad_ws_floats': (i64, [i32, i32, i64]),
+    'mo_conv1x1_bwd_weight': (i32, [vp, i32, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    'mo_adp_fwd': (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    'mo_adp_bwd': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp]),
+    'mo_tcn_pack_weights': (i32, [vp, vp, i32, vp, vp]),
+    'mo_tcn_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp]),
+    'mo_tcn_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, vp,
+                         vp, vp, vp]),
+    'mo_spmm_csr': (i32, [vp, vp, vp, i32, vp, vp, i64, i32, vp]),
+    'mo_adj_gemm': (i32, [vp, i32, vp, vp, i64, i32, vp]),
+    'mo_adj_grad': (i32, [vp, vp, i32, i64, vp, i32, vp]),
+    'mo_mlp_partial_floats': (i64, [i64]),
+    'mo_gcn_mlp_fwd': (i32, [vp, i32, vp, vp, i64, i32, i32, vp, vp, vp, u32, u32, f32, vp, vp, vp]),
+    'mo_bn_finalize': (i32, [vp, i64, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
+    'mo_bn_bwd': (i32, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'mo_gcn_mlp_bwd': (i32, [vp, vp, vp, i32, vp, i64, u32, u32, f32, vp, vp, vp, vp]),
+    'mo_metrics_ws_floats': (i64, [i64]),
+    'mo_mse_metrics': (i32, [vp, vp, i64, vp, vp, vp, vp]),
+    'mo_date2vec_encode': (i32, [vp, i64, vp, vp, i32, vp, vp, i32, vp, vp]),
+    'mo_colsum': (i32, [vp, i64, i32, vp, vp, vp]),
+    'mo_colsum_ws_floats': (i64, [i64, i32]),
+    'mo_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, vp]),
+}
+
+
+def load():
+    """Load libmo_hip.so (built in-tree by multimodal_outage_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
+            'Build it with `python -m multimodal_outage_amd.build`.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = load().mo_strerror(code).decode()
+        raise RuntimeError(f'mo_hip {what}: {msg} (code {code})')
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, or NULL."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'mo_hip ops need contiguous device tensors'
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,348 @@
+// Tiled fp32 MFMA contraction engine for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma).
+//
+// One kernel template computes  D[m][n] = epilogue( sum_k A(m,k) * B(k,n) )  where each operand is a
+// "virtual matrix" described at run time (MoOperand): a concatenation of column segments, each a
+// row-major [rows][ld] fp32 array with an optional row map (time-crop / dilation tap / left pad),
+// per-column affine (folded BatchNorm), ReLU and regenerated dropout mask applied on load.
+// This is what lets the 1x1 convs, the dilated gated TCN, the gcn mlp over the never-materialised
+// channel concat, their data/weight gradients and the dense adaptive-adjacency products all run on
+// the same LDS-staged MFMA loop.
+//
+// Operand modes (which index enumerates the source rows):
+//   KROWS: source rows = k, source columns = m (or n): tile copy is a straight row copy
+//   XROWS: source rows = m (or n), source columns = k: tile copy transposes through LDS
+// LDS tiles are always [BK][BX+pad] so that the MFMA fragment read (lane i=l&31, kk=l>>5 reads
+// T[k+kk][x0+i]) is a conflict-free ds_read_b32.
+#pragma once
+#include "mo_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MO_MAX_SEG 8
+#define MO_KROWS 0
+#define MO_XROWS 1
+
+struct MoSeg {
+  const float* ptr;
+  const float* scale;  // optional per-column affine (index = column within segment)
+  const float* shift;
+  int ld;
+  int To, Ti, off;     // row map r -> (g=r/To, t=r%To+off) -> g*Ti+t, valid iff 0<=t<Ti; To==0: identity
+  int relu;
+  uint32_t drop_seed, drop_thresh;  // drop_thresh==0: no dropout; element index = srow*ld + col
+  float drop_scale;
+  int pad_;
+};
+
+struct MoOperand {
+  MoSeg seg[MO_MAX_SEG];
+  int nseg;   // segments concatenated along the column direction
+  int segw;   // columns per segment (nseg>1); unused for nseg==1
+  int rows;   // logical extent along the row direction
+  int cols;   // logical extent along the column direction
+};
+
+enum { MO_EPI_STORE = 0, MO_EPI_GATE = 1, MO_EPI_GATE_BWD = 2, MO_EPI_MLP = 3 };
+
+struct MoEpi {
+  float* out[MO_MAX_SEG];  // outputs, segmented along n when nout>1 (n -> out[n/osegw][.., n%osegw])
+  int nout, osegw;
+  int ldo;
+  int oTo, oTi, ooff;      // output row map (oTo==0: identity); unmapped rows are skipped
+  const float* bias;       // per n
+  const float* bias2;      // GATE*: gate bias
+  int relu;
+  int beta;                // 1: accumulate into out
+  const float* mask;       // multiply by (mask[m*ldmask+n] > 0)   (ReLU backward)
+  int ldmask;
+  const float* add;        // add source with its own row map and affine (residual / crop-add)
+  int ldadd, aTo, aTi, aoff;
+  const float* ascale;
+  const float* ashift;
+  const float* aux;        // GATE_BWD: upstream gradient dg[m][32]
+  int ldaux;
+  uint32_t drop_seed, drop_thresh;
+  float drop_scale;
+  float* partial;          // MLP: per-block BatchNorm partial sums [gridDim.x][64] (sum | sumsq)
+  long slab_stride;        // split-K: slab z goes to out + z*slab_stride
+  int kchunk;              // split-K chunk (multiple of BK); 0: whole K
+};
+
+__device__ __forceinline__ bool mo_seg_row(const MoSeg& s, int r, long& srow) {
+  if (s.To == 0) { srow = r; return true; }
+  int g = r / s.To;
+  int t = r - g * s.To + s.off;
+  srow = (long)g * s.Ti + t;
+  return (t >= 0) && (t < s.Ti);
+}
+
+__device__ __forceinline__ float mo_post(const MoSeg& s, float v, int cc, long srow) {
+  if (s.scale) v = v * s.scale[cc] + s.shift[cc];
+  if (s.relu) v = fmaxf(v, 0.f);
+  if (s.drop_thresh) {
+    uint32_t h = mo_hash32(s.drop_seed, (uint32_t)(srow * s.ld + cc));
+    v = (h >= s.drop_thresh) ? v * s.drop_scale : 0.f;
+  }
+  return v;
+}
+
+// Four consecutive columns c..c+3 of logical row r (zero where out of range / unmapped).
+__device__ __forceinline__ float4 mo_fetch4(const MoSeg* segs, int nseg, int segw, int rows, int cols,
+                                            int r, int c) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r >= rows || c >= cols) return v;
+  int s = 0, cc = c, w = cols;
+  if (nseg > 1) { s = c / segw; cc = c - s * segw; w = segw; }
+  const MoSeg& sg = segs[s];
+  long srow;
+  if (!mo_seg_row(sg, r, srow)) return v;
+  const float* p = sg.ptr + srow * (long)sg.ld + cc;
+  bool vec = ((sg.ld & 3) == 0) && ((((uintptr_t)sg.ptr) & 15) == 0) && (cc + 3 < w);
+  if (vec) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (cc + 0 < w) v.x = p[0];
+    if (cc + 1 < w) v.y = p[1];
+    if (cc + 2 < w) v.z = p[2];
+    if (cc + 3 < w) v.w = p[3];
+  }
+  if (sg.scale || sg.relu || sg.drop_thresh) {
+    if (cc + 0 < w) v.x = mo_post(sg, v.x, cc + 0, srow);
+    if (cc + 1 < w) v.y = mo_post(sg, v.y, cc + 1, srow);
+    if (cc + 2 < w) v.z = mo_post(sg, v.z, cc + 2, srow);
+    if (cc + 3 < w) v.w = mo_post(sg, v.w, cc + 3, srow);
+  }
+  return v;
+}
+
+template <int BX, int BK, int NT, int MODE>
+struct MoTile {
+  static constexpr int PAD = (MODE == MO_KROWS) ? 4 : 1;
+  static constexpr int LD = BX + PAD;
+  static constexpr int NV = (BK * BX / 4) / NT;  // float4 per thread per tile
+  static_assert((BK * BX / 4) % NT == 0, "tile/thread mismatch");
+
+  __device__ __forceinline__ static void load(float4 (&reg)[NV], const MoSeg* segs, int nseg, int segw,
+                                              int rows, int cols, int x0, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = tid + i * NT;
+      if (MODE == MO_KROWS) {
+        int k = f / (BX / 4), x4 = f % (BX / 4);
+        reg[i] = mo_fetch4(segs, nseg, segw, rows, cols, k0 + k, x0 + 4 * x4);
+      } else {
+        int x = f / (BK / 4), k4 = f % (BK / 4);
+        reg[i] = mo_fetch4(segs, nseg, segw, rows, cols, x0 + x, k0 + 4 * k4);
+      }
+    }
+  }
+  __device__ __forceinline__ static void store(const float4 (&reg)[NV], float* T, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = tid + i * NT;
+      if (MODE == MO_KROWS) {
+        int k = f / (BX / 4), x4 = f % (BX / 4);
+        *reinterpret_cast<float4*>(&T[k * LD + 4 * x4]) = reg[i];
+      } else {
+        int x = f / (BK / 4), k4 = f % (BK / 4);
+        T[(4 * k4 + 0) * LD + x] = reg[i].x;
+        T[(4 * k4 + 1) * LD + x] = reg[i].y;
+        T[(4 * k4 + 2) * LD + x] = reg[i].z;
+        T[(4 * k4 + 3) * LD + x] = reg[i].w;
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ float mo_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI>
+__global__ void __launch_bounds__(WM* WN * 64)
+mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int SM = BM / WM, SN = BN / WN;
+  constexpr int TM = SM / 32, TN = SN / 32;
+  static_assert(SM % 32 == 0 && SN % 32 == 0, "wave tile must be a multiple of 32x32");
+  using TA = MoTile<BM, BK, NT, AMODE>;
+  using TB = MoTile<BN, BK, NT, BMODE>;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK * TA::LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * TB::LD];
+  __shared__ MoSeg sA[MO_MAX_SEG];
+  __shared__ MoSeg sB[MO_MAX_SEG];
+  __shared__ float red[(EPI == MO_EPI_MLP) ? WM * WN * 64 : 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WN) * SM;
+  const int wn0 = (wave % WN) * SN;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // stage operand descriptors in LDS (segment index may vary per lane)
+  if (tid < MO_MAX_SEG) { sA[tid] = A.seg[tid]; sB[tid] = B.seg[tid]; }
+  __syncthreads();
+
+  // logical extents: M, N from the x-direction of each operand, K from the k-direction
+  const int K = (AMODE == MO_KROWS) ? A.rows : A.cols;
+  int kbeg = 0, kend = K;
+  if (E.kchunk > 0) {
+    kbeg = blockIdx.z * E.kchunk;
+    kend = min(K, kbeg + E.kchunk);
+  }
+  const int a_rows = A.rows, a_cols = A.cols, b_rows = B.rows, b_cols = B.cols;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[TA::NV], rb[TB::NV];
+  const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  // Bound the k direction by kend as well (split-K chunks end on BK multiples except the last,
+  // which ends at K == rows/cols, so the operand's own extent check is sufficient).
+  if (nk > 0) {
+    TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, m0, kbeg, tid);
+    TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, n0, kbeg, tid);
+    TA::store(ra, As[0], tid);
+    TB::store(rb, Bs[0], tid);
+  }
+  __syncthreads();
+
+  const int fi = lane & 31, fk = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, m0, kbeg + (kt + 1) * BK, tid);
+      TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, n0, kbeg + (kt + 1) * BK, tid);
+    }
+    const float* Ac = As[cur];
+    const float* Bc = Bs[cur];
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ac[(2 * ks + fk) * TA::LD + wm0 + i * 32 + fi];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bc[(2 * ks + fk) * TB::LD + wn0 + j * 32 + fi];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      TA::store(ra, As[cur ^ 1], tid);
+      TB::store(rb, Bs[cur ^ 1], tid);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const int M = (AMODE == MO_KROWS) ? A.cols : A.rows;
+  const int N = (BMODE == MO_KROWS) ? B.cols : B.rows;
+
+  if (EPI == MO_EPI_STORE) {
+    float* const obase_off = nullptr;
+    (void)obase_off;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + fi;
+        if (n >= N) continue;
+        int os = 0, on = n;
+        if (E.nout > 1) { os = n / E.osegw; on = n - os * E.osegw; }
+        float* obase = E.out[os] + (long)blockIdx.z * E.slab_stride;
+        const float bv = E.bias ? E.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+          if (m >= M) continue;
+          float v = acc[i][j][r] + bv;
+          if (E.add) {
+            int g = m, t = 0; long arow = m; bool ok = true;
+            if (E.aTo) { g = m / E.aTo; t = m - g * E.aTo + E.aoff; arow = (long)g * E.aTi + t; ok = (t >= 0) && (t < E.aTi); }
+            if (ok) {
+              float av = E.add[arow * E.ldadd + n];
+              if (E.ascale) av = av * E.ascale[n] + E.ashift[n];
+              v += av;
+            }
+          }
+          if (E.relu) v = fmaxf(v, 0.f);
+          if (E.mask) v = (E.mask[(long)m * E.ldmask + n] > 0.f) ? v : 0.f;
+          long orow = m;
+          if (E.oTo) {
+            int g = m / E.oTo; int t = m - g * E.oTo + E.ooff;
+            if (t < 0 || t >= E.oTi) continue;
+            orow = (long)g * E.oTi + t;
+          }
+          float* o = obase + orow * E.ldo + on;
+          if (E.beta) v += *o;
+          *o = v;
+        }
+      }
+    }
+  } else if (EPI == MO_EPI_GATE || EPI == MO_EPI_GATE_BWD) {
+    // TN == 2: acc[i][0] = filter pre-activation, acc[i][1] = gate pre-activation, same (row, col)
+    const int c = fi;  // channel 0..31
+    const float bf = E.bias[c], bg = E.bias2[c];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (m >= M) continue;
+        const float f = tanhf(acc[i][0][r] + bf);
+        const float g = mo_sigmoid(acc[i][TN - 1][r] + bg);
+        if (EPI == MO_EPI_GATE) {
+          E.out[0][(long)m * E.ldo + c] = f * g;
+        } else {
+          const float dg = E.aux[(long)m * E.ldaux + c];
+          E.out[0][(long)m * E.ldo + c] = dg * g * (1.f - f * f);
+          E.out[0][(long)m * E.ldo + 32 + c] = dg * f * g * (1.f - g);
+        }
+      }
+    }
+  } else if (EPI == MO_EPI_MLP) {
+    // BN == 32 (TN == 1, WN == 1): bias + dropout + residual(affine, row map) -> h; BN partial sums.
+    const int n = fi;
+    const float bv = E.bias[n];
+    const float asc = E.ascale ? E.ascale[n] : 1.f;
+    const float ash = E.ashift ? E.ashift[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (m >= M) continue;
+        float v = acc[i][0][r] + bv;
+        if (E.drop_thresh) {
+          uint32_t h = mo_hash32(E.drop_seed, (uint32_t)((long)m * E.ldo + n));
+          v = (h >= E.drop_thresh) ? v * E.drop_scale : 0.f;
+        }
+        int g = m / E.aTo; int t = m - g * E.aTo + E.aoff;
+        const float rv = E.add[((long)g * E.aTi + t) * E.ldadd + n] * asc + ash;
+        v += rv;
+        E.out[0][(long)m * E.ldo + n] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (lane < 32) { red[wave * 64 + lane] = s1; red[wave * 64 + 32 + lane] = s2; }
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM * WN; ++w) t += red[w * 64 + tid];
+      E.partial[(long)blockIdx.x * 64 + tid] = t;
+    }
+  }
+}

@@ -1,0 +1,314 @@
+"""Host-side orchestration of the Graph-WaveNet forward/backward on the HIP C-ABI.
+
+One ``torch.autograd.Function`` spans the whole network body (graph_wavenet.py:191-254); torch only
+owns the buffers and carries the gradients to the parameter tensors.  Internal activations live in
+the node-major channels-last "nbtc" layout (rows p=(n*B+b)*T+t of 32 channels), so every node-axis
+product is a row operation on [N][B*T*32] and every channel contraction a GEMM over rows.
+
+BatchNorm of layer i is never materialised: the kernels that consume x_{i+1} = BN(h_i) apply the
+folded affine (scale, shift) on load (tcn / residual), and the backward recomputes xhat from h_i.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def csr_from_dense(a):
+    """Row-major CSR (rowptr, colidx int32; vals float32) of a dense matrix: the same ordering as
+    scipy.sparse.csr_matrix(a) (rows ascending, columns ascending within a row)."""
+    a = np.asarray(a, dtype=np.float32)
+    rows, cols = np.nonzero(a)
+    rowptr = np.zeros(a.shape[0] + 1, dtype=np.int32)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    return rowptr, cols.astype(np.int32), a[rows, cols].astype(np.float32)
+
+
+class StaticSupport:
+    """A static support A (N,N): CSR of A^T for the forward nconv (out[w] = sum_v A[v,w] x[v],
+    graph_wavenet.py:65) and CSR of A for its backward."""
+
+    def __init__(self, dense, device):
+        dense = np.asarray(dense, dtype=np.float32)
+        self.n = dense.shape[0]
+        self.fwd = tuple(torch.from_numpy(x).to(device) for x in csr_from_dense(dense.T))
+        self.bwd = tuple(torch.from_numpy(x).to(device) for x in csr_from_dense(dense))
+        self.nnz = int(self.fwd[1].numel())
+
+
+def _e(n, w, dev):
+    return torch.empty((n, w), device=dev, dtype=torch.float32)
+
+
+class GwnetConfig:
+    def __init__(self, *, num_nodes, in_dim, out_dim, kernel_size, blocks, layers, skip_channels,
+                 end_channels, gcn, adaptive, dropout, names):
+        self.N, self.Cin, self.Cout, self.K = num_nodes, in_dim, out_dim, kernel_size
+        self.blocks, self.layers = blocks, layers
+        self.L = blocks * layers
+        self.dil = [2 ** i for _ in range(blocks) for i in range(layers)]
+        self.rf = 1 + sum((kernel_size - 1) * d for d in self.dil)
+        self.Cs, self.Ce = skip_channels, end_channels
+        self.gcn, self.adaptive, self.dropout = gcn, adaptive, dropout
+        self.names = names            # parameter order of the autograd Function
+
+
+def _spmm(csr, n, X, Y, J, beta):
+    L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), n, L.ptr(X), L.ptr(Y), J, beta,
+           L.stream())
+
+
+class GwnetFunction(torch.autograd.Function):
+    """y = gwnet_body(x; params).  x: (B,Cin,N,T) fp32 contiguous on the GPU."""
+
+    @staticmethod
+    def forward(ctx, cfg, statics, bn_bufs, training, x, *params):
+        p = dict(zip(cfg.names, params))
+        dev = x.device
+        st = L.stream()
+        B, Cin, N, T = x.shape
+        assert Cin == cfg.Cin and N == cfg.N
+        x = x.contiguous()
+        G = N * B
+        K = cfg.K
+        Tp = max(T, cfg.rf)
+        pad = Tp - T
+        Tf = Tp - (cfg.rf - 1)
+        saved = {}
+
+        x_int = _e(G * T, Cin, dev)
+        L.call('mo_nchw_to_nbtc', L.ptr(x), L.ptr(x_int), B, Cin, N, T, st)
+        h = _e(G * Tp, 32, dev)
+        L.call('mo_conv1x1_fwd', L.ptr(x_int), Cin, Tp, T, -pad, 0, L.ptr(p['start_conv.weight']),
+               L.ptr(p['start_conv.bias']), 32, L.ptr(h), G * Tp, 0, 0, st)
+        adp = adpT = None
+        if cfg.gcn and cfg.adaptive:
+            adp = _e(N, N, dev)
+            adpT = _e(N, N, dev)
+            L.call('mo_adp_fwd', L.ptr(p['nodevec1']), L.ptr(p['nodevec2']), N, p['nodevec1'].shape[1],
+                   L.ptr(adp), L.ptr(adpT), st)
+        skip = _e(G * Tf, cfg.Cs, dev)
+        drop_p = cfg.dropout if training else 0.0
+        thresh = int(min(max(drop_p, 0.0), 0.999999) * 4294967296.0) if drop_p > 0 else 0
+        dscale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        base_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if thresh else 0
+
+        scale = shift = None
+        Tin = Tp
+        layers = []
+        for i in range(cfg.L):
+            d = cfg.dil[i]
+            Tout = Tin - d * (K - 1)
+            P = G * Tout
+            J = B * Tout * 32
+            Wp = torch.empty(K * 64 * 32, device=dev, dtype=torch.float32)
+            L.call('mo_tcn_pack_weights', L.ptr(p[f'filter_convs.{i}.weight']),
+                   L.ptr(p[f'gate_convs.{i}.weight']), K, L.ptr(Wp), st)
+            g = _e(P, 32, dev)
+            L.call('mo_tcn_fwd', L.ptr(h), L.ptr(scale), L.ptr(shift), L.ptr(Wp),
+                   L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, d, G, Tin,
+                   L.ptr(g), st)
+            L.call('mo_conv1x1_fwd', L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
+                   L.ptr(p[f'skip_convs.{i}.weight']), L.ptr(p[f'skip_convs.{i}.bias']), cfg.Cs,
+                   L.ptr(skip), G * Tf, 0, 1 if i > 0 else 0, st)
+            srcs = [g]
+            if cfg.gcn:
+                for s in statics:
+                    x1 = _e(P, 32, dev)
+                    x2 = _e(P, 32, dev)
+                    _spmm(s.fwd, N, g, x1, J, 0)
+                    _spmm(s.fwd, N, x1, x2, J, 0)
+                    srcs += [x1, x2]
+                if cfg.adaptive:
+                    x1 = _e(P, 32, dev)
+                    x2 = _e(P, 32, dev)
+                    L.call('mo_adj_gemm', L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, st)
+                    L.call('mo_adj_gemm', L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, st)
+                    srcs += [x1, x2]
+                W, bb = p[f'gconv.{i}.mlp.mlp.weight'], p[f'gconv.{i}.mlp.mlp.bias']
+                lt, ls, seed = thresh, dscale, (base_seed + 7919 * i) & 0xFFFFFFFF
+            else:
+                W, bb = p[f'residual_convs.{i}.weight'], p[f'residual_convs.{i}.bias']
+                lt, ls, seed = 0, 1.0, 0
+            hn = _e(P, 32, dev)
+            nblk = (P + 127) // 128
+            partial = torch.empty(L.load().mo_mlp_partial_floats(P), device=dev, dtype=torch.float32)
+            L.call('mo_gcn_mlp_fwd', L.ptr_array(srcs), len(srcs), L.ptr(W), L.ptr(bb), G, Tout, Tin,
+                   L.ptr(h), L.ptr(scale), L.ptr(shift), seed, lt, ls, L.ptr(hn), L.ptr(partial), st)
+            stats = torch.empty(4, 32, device=dev, dtype=torch.float32)   # scale, shift, mean, rstd
+            rm, rv = bn_bufs[i]
+            L.call('mo_bn_finalize', L.ptr(partial), nblk, P, L.ptr(p[f'bn.{i}.weight']),
+                   L.ptr(p[f'bn.{i}.bias']), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, 1 if training else 0,
+                   L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), st)
+            layers.append(dict(h_in=h, scale=scale, shift=shift, Wp=Wp, g=g, srcs=srcs, h=hn,
+                               stats=stats, Tin=Tin, Tout=Tout, seed=seed, thresh=lt, dscale=ls))
+            h, scale, shift, Tin = hn, stats[0], stats[1], Tout
+
+        P_f = G * Tf
+        r1 = _e(P_f, cfg.Ce, dev)
+        L.call('mo_conv1x1_fwd', L.ptr(skip), cfg.Cs, 0, 0, 0, 1, L.ptr(p['end_conv_1.weight']),
+               L.ptr(p['end_conv_1.bias']), cfg.Ce, L.ptr(r1), P_f, 1, 0, st)
+        y_int = _e(P_f, cfg.Cout, dev)
+        L.call('mo_conv1x1_fwd', L.ptr(r1), cfg.Ce, 0, 0, 0, 0, L.ptr(p['end_conv_2.weight']),
+               L.ptr(p['end_conv_2.bias']), cfg.Cout, L.ptr(y_int), P_f, 0, 0, st)
+        y = torch.empty((B, cfg.Cout, N, Tf), device=dev, dtype=torch.float32)
+        L.call('mo_nbtc_to_nchw', L.ptr(y_int), L.ptr(y), B, cfg.Cout, N, Tf, st)
+
+        ctx.cfg, ctx.statics, ctx.training = cfg, statics, training
+        ctx.dims = (B, N, T, Tp, Tf, G)
+        ctx.layers, ctx.x_int, ctx.adp, ctx.adpT, ctx.skip, ctx.r1 = layers, x_int, adp, adpT, skip, r1
+        ctx.params = p
+        ctx.x_needs_grad = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, statics, p = ctx.cfg, ctx.statics, ctx.params
+        if not ctx.training:
+            raise RuntimeError('gwnet backward is only defined in training mode (batch-stat BatchNorm)')
+        lib = L.load()
+        B, N, T, Tp, Tf, G = ctx.dims
+        K = cfg.K
+        dev = dy.device
+        st = L.stream()
+        grads = {k: None for k in cfg.names}
+
+        def ws_for(M, Nn, P):
+            return torch.empty(lib.mo_wgrad_ws_floats(M, Nn, P), device=dev, dtype=torch.float32)
+
+        # ---- head (graph_wavenet.py:252-254)
+        P_f = G * Tf
+        dy = dy.contiguous()
+        dy_int = _e(P_f, cfg.Cout, dev)
+        L.call('mo_nchw_to_nbtc', L.ptr(dy), L.ptr(dy_int), B, cfg.Cout, N, Tf, st)
+        skip, r1 = ctx.skip, ctx.r1
+        ws = ws_for(max(cfg.Ce, cfg.Cout), max(cfg.Ce, cfg.Cs), P_f)
+        gW2 = torch.empty_like(p['end_conv_2.weight']); gb2 = torch.empty_like(p['end_conv_2.bias'])
+        L.call('mo_conv1x1_bwd_weight', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(r1), cfg.Ce, 0, 0, 0, 0,
+               L.ptr(gW2), L.ptr(gb2), L.ptr(ws), st)
+        da1 = _e(P_f, cfg.Ce, dev)
+        L.call('mo_conv1x1_bwd_data', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(p['end_conv_2.weight']), cfg.Ce,
+               L.ptr(da1), 0, 0, 0, L.ptr(r1), 0, st)
+        gW1 = torch.empty_like(p['end_conv_1.weight']); gb1 = torch.empty_like(p['end_conv_1.bias'])
+        L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, P_f, L.ptr(skip), cfg.Cs, 0, 0, 0, 1,
+               L.ptr(gW1), L.ptr(gb1), L.ptr(ws), st)
+        dskip = _e(P_f, cfg.Cs, dev)
+        L.call('mo_conv1x1_bwd_data', L.ptr(da1), cfg.Ce, P_f, L.ptr(p['end_conv_1.weight']), cfg.Cs,
+               L.ptr(dskip), 0, 0, 0, L.ptr(skip), 0, st)
+        grads['end_conv_2.weight'], grads['end_conv_2.bias'] = gW2, gb2
+        grads['end_conv_1.weight'], grads['end_conv_1.bias'] = gW1, gb1
+        dbs = torch.empty(cfg.Cs, device=dev, dtype=torch.float32)
+        L.call('mo_colsum', L.ptr(dskip), P_f, cfg.Cs, L.ptr(dbs), L.ptr(ws), st)
+
+        dAdp = None
+        if cfg.gcn and cfg.adaptive:
+            dAdp = _e(N, N, dev)
+        dAdp_started = False
+        dxo = None            # gradient w.r.t. the BatchNorm output of the current layer
+        for i in reversed(range(cfg.L)):
+            ly = ctx.layers[i]
+            Tin, Tout = ly['Tin'], ly['Tout']
+            P = G * Tout
+            J = B * Tout * 32
+            g = ly['g']
+            srcs = ly['srcs']
+            ns = len(srcs)
+            dh = None
+            if dxo is not None:
+                # BatchNorm backward (graph_wavenet.py:250)
+                dh = _e(P, 32, dev)
+                gg = torch.empty(32, device=dev); gb = torch.empty(32, device=dev)
+                wsb = torch.empty(lib.mo_mlp_partial_floats(P) + 64, device=dev, dtype=torch.float32)
+                L.call('mo_bn_bwd', L.ptr(dxo), L.ptr(ly['h']), P, L.ptr(p[f'bn.{i}.weight']),
+                       L.ptr(ly['stats'][2]), L.ptr(ly['stats'][3]), L.ptr(dh), L.ptr(gg), L.ptr(gb),
+                       L.ptr(wsb), st)
+                grads[f'bn.{i}.weight'], grads[f'bn.{i}.bias'] = gg, gb
+                # mlp / residual-conv backward (graph_wavenet.py:95-97 / :245)
+                dsrcs = [_e(P, 32, dev) for _ in range(ns)]
+                if cfg.gcn:
+                    W = p[f'gconv.{i}.mlp.mlp.weight']
+                    kW, kb = f'gconv.{i}.mlp.mlp.weight', f'gconv.{i}.mlp.mlp.bias'
+                else:
+                    W = p[f'residual_convs.{i}.weight']
+                    kW, kb = f'residual_convs.{i}.weight', f'residual_convs.{i}.bias'
+                gW = torch.empty_like(W); gbm = torch.empty(32, device=dev)
+                wsm = ws_for(32, 32 * ns, P)
+                L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
+                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), L.ptr(wsm), st)
+                grads[kW], grads[kb] = gW, gbm
+                dg = dsrcs[0]
+                k = 1
+                if cfg.gcn:
+                    for s in statics:
+                        dx1, dx2 = dsrcs[k], dsrcs[k + 1]
+                        _spmm(s.bwd, N, dx2, dx1, J, 1)
+                        _spmm(s.bwd, N, dx1, dg, J, 1)
+                        k += 2
+                    if cfg.adaptive:
+                        x1 = srcs[k]
+                        dx1, dx2 = dsrcs[k], dsrcs[k + 1]
+                        L.call('mo_adj_gemm', L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, st)
+                        L.call('mo_adj_grad', L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
+                               1 if dAdp_started else 0, st)
+                        dAdp_started = True
+                        L.call('mo_adj_gemm', L.ptr(ctx.adpT), N, L.ptr(dx1), L.ptr(dg), J, 1, st)
+                        L.call('mo_adj_grad', L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, st)
+                beta = 1
+            else:
+                dg = torch.zeros((P, 32), device=dev, dtype=torch.float32)
+                beta = 1
+            # skip path (graph_wavenet.py:230-236): dg[crop] += dskip @ Ws ; dWs
+            Ws = p[f'skip_convs.{i}.weight']
+            L.call('mo_conv1x1_bwd_data', L.ptr(dskip), cfg.Cs, P_f, L.ptr(Ws), 32, L.ptr(dg), Tf, Tout,
+                   Tout - Tf, None, beta, st)
+            gWs = torch.empty_like(Ws)
+            wss = ws_for(cfg.Cs, 32, P_f)
+            L.call('mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
+                   L.ptr(gWs), None, L.ptr(wss), st)
+            grads[f'skip_convs.{i}.weight'], grads[f'skip_convs.{i}.bias'] = gWs, dbs
+            # gated TCN backward (graph_wavenet.py:222-226) + residual (:247)
+            du = _e(G * Tin, 32, dev)
+            gWf = torch.empty_like(p[f'filter_convs.{i}.weight']); gWg = torch.empty_like(gWf)
+            gbf = torch.empty(32, device=dev); gbg = torch.empty(32, device=dev)
+            dpre = _e(P, 64, dev)
+            ws2 = ws_for(64, 32 * K, P)
+            L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
+                   L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, cfg.dil[i], G,
+                   Tin, L.ptr(dg), L.ptr(dh), L.ptr(du), L.ptr(gWf), L.ptr(gWg), L.ptr(gbf), L.ptr(gbg),
+                   L.ptr(dpre), L.ptr(ws2), st)
+            grads[f'filter_convs.{i}.weight'], grads[f'filter_convs.{i}.bias'] = gWf, gbf
+            grads[f'gate_convs.{i}.weight'], grads[f'gate_convs.{i}.bias'] = gWg, gbg
+            dxo = du
+
+        # ---- start conv (graph_wavenet.py:191-196)
+        pad = Tp - T
+        Wst = p['start_conv.weight']
+        gWst = torch.empty_like(Wst); gbst = torch.empty(32, device=dev)
+        wst = ws_for(32, cfg.Cin, G * Tp)
+        L.call('mo_conv1x1_bwd_weight', L.ptr(dxo), 32, G * Tp, L.ptr(ctx.x_int), cfg.Cin, Tp, T, -pad, 0,
+               L.ptr(gWst), L.ptr(gbst), L.ptr(wst), st)
+        grads['start_conv.weight'], grads['start_conv.bias'] = gWst, gbst
+        dx = None
+        if ctx.x_needs_grad:
+            dx_int = _e(G * T, cfg.Cin, dev)
+            L.call('mo_conv1x1_bwd_data', L.ptr(dxo), 32, G * Tp, L.ptr(Wst), cfg.Cin, L.ptr(dx_int), Tp, T,
+                   -pad, None, 0, st)
+            dx = torch.empty((B, cfg.Cin, N, T), device=dev, dtype=torch.float32)
+            L.call('mo_nbtc_to_nchw', L.ptr(dx_int), L.ptr(dx), B, cfg.Cin, N, T, st)
+
+        # ---- adaptive adjacency (graph_wavenet.py:202)
+        if dAdp is not None:
+            E1, E2 = p['nodevec1'], p['nodevec2']
+            R = E1.shape[1]
+            if dAdp_started:
+                gE1 = torch.empty_like(E1); gE2 = torch.empty_like(E2)
+                nz = (N + 127) // 128
+                wsa = torch.empty(nz * R * N, device=dev, dtype=torch.float32)
+                L.call('mo_adp_bwd', L.ptr(E1), L.ptr(E2), L.ptr(ctx.adp), L.ptr(dAdp), N, R, L.ptr(gE1),
+                       L.ptr(gE2), L.ptr(wsa), wsa.numel(), st)
+            else:
+                gE1 = torch.zeros_like(E1); gE2 = torch.zeros_like(E2)
+            grads['nodevec1'], grads['nodevec2'] = gE1, gE2
+
+        return (None, None, None, None, dx) + tuple(grads[k] for k in cfg.names)

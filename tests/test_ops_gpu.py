@@ -1,0 +1,403 @@
+"""GPU parity tests, op level: every C-ABI entry point against a plain fp32 torch CPU restatement of
+the same op (tolerance 1e-4 relative to the tensor scale, the north-star bound for fp32).  The calls
+go through the ctypes C-ABI (multimodal_outage_amd._lib)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rand, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def L():
+    import multimodal_outage_amd._lib as lib
+    lib.load()
+    return lib
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def nbtc(x):
+    """(B,C,N,T) -> rows (n,b,t) of C channels."""
+    B, C, N, T = x.shape
+    return x.permute(2, 0, 3, 1).reshape(N * B * T, C).contiguous()
+
+
+def from_nbtc(y, B, C, N, T):
+    return y.reshape(N, B, T, C).permute(1, 3, 0, 2).contiguous()
+
+
+def close(a, b, tol=1e-4, what=''):
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(b).double()
+    a = a.detach().cpu().double()
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max())
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert err <= tol * scale + 1e-7, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.parametrize('B,C,N,T', [(1, 320, 67, 7), (4, 2, 20, 12), (3, 5, 37, 5), (2, 33, 70, 13)])
+def test_layout_roundtrip(L, B, C, N, T):
+    x = rand(1, (B, C, N, T))
+    xd = dev(x)
+    y = torch.empty(N * B * T, C, device='cuda')
+    L.call('mo_nchw_to_nbtc', L.ptr(xd), L.ptr(y), B, C, N, T, L.stream())
+    assert torch.equal(y.cpu(), nbtc(x))
+    z = torch.empty_like(xd)
+    L.call('mo_nbtc_to_nchw', L.ptr(y), L.ptr(z), B, C, N, T, L.stream())
+    assert torch.equal(z.cpu(), x)
+
+
+def _rowmap(inp, G, To, Ti, off):
+    """gather rows: out[(g,t)] = inp[g*Ti + t + off] or 0."""
+    C = inp.shape[1]
+    out = torch.zeros(G * To, C)
+    for t in range(To):
+        tt = t + off
+        if 0 <= tt < Ti:
+            out[t::To] = inp[tt::Ti]
+    return out
+
+
+@pytest.mark.parametrize('Ci,Co,G,To,Ti,off,in_relu,out_relu,beta', [
+    (2, 32, 80, 13, 12, -1, 0, 0, 0),       # start conv with left pad, tiny Cin (unaligned rows)
+    (5, 32, 111, 13, 5, -8, 0, 0, 0),
+    (320, 32, 67, 7, 7, 0, 0, 0, 0),        # reference start conv
+    (32, 256, 90, 1, 12, 11, 0, 0, 1),      # skip conv with crop + accumulate
+    (32, 256, 67, 7, 7, 0, 0, 0, 0),
+    (256, 512, 300, 0, 0, 0, 1, 1, 0),      # head 1: relu in, relu out
+    (512, 12, 300, 0, 0, 0, 0, 0, 0),       # head 2
+    (512, 255, 77, 0, 0, 0, 0, 0, 0),
+    (4096, 1024, 14, 0, 0, 0, 0, 1, 0),     # Encoder fc1 (unet.py:142)
+])
+def test_conv1x1_fwd_bwd(L, Ci, Co, G, To, Ti, off, in_relu, out_relu, beta):
+    P_in = G * (Ti if To else 1)
+    P_out = G * (To if To else 1)
+    x = rand(2, (P_in, Ci))
+    W = rand(3, (Co, Ci)) / np.sqrt(Ci)
+    b = rand(4, (Co,))
+    xin = _rowmap(x, G, To, Ti, off) if To else x
+    if in_relu:
+        xin = xin.relu()
+    pre = xin @ W.t() + b
+    ref = pre.relu() if out_relu else pre
+    out0 = rand(5, (P_out, Co))
+    out = dev(out0.clone())
+    L.call('mo_conv1x1_fwd', L.ptr(dev(x)), Ci, To, Ti, off, in_relu, L.ptr(dev(W)), L.ptr(dev(b)), Co,
+           L.ptr(out), P_out, out_relu, beta, L.stream())
+    close(out, ref + (out0 if beta else 0), what='fwd')
+
+    # weight gradient
+    dout = rand(6, (P_out, Co))
+    lib = L.load()
+    ws = torch.empty(lib.mo_wgrad_ws_floats(Co, Ci, P_out), device='cuda')
+    dW = torch.empty(Co, Ci, device='cuda')
+    db = torch.empty(Co, device='cuda')
+    L.call('mo_conv1x1_bwd_weight', L.ptr(dev(dout)), Co, P_out, L.ptr(dev(x)), Ci, To, Ti, off, in_relu,
+           L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+    close(dW, dout.t() @ xin, what='dW')
+    close(db, dout.sum(0), what='db')
+
+
+@pytest.mark.parametrize('Co,Ci,G,oTo,oTi,ooff,use_mask,beta', [
+    (256, 32, 90, 1, 12, 11, False, 1),     # skip bwd into cropped rows of dg
+    (256, 32, 67, 7, 7, 0, False, 0),
+    (12, 512, 300, 0, 0, 0, True, 0),       # head2 bwd with relu mask
+    (512, 256, 200, 0, 0, 0, True, 0),
+    (32, 2, 80, 13, 12, -1, False, 0),      # start conv bwd (pad rows dropped)
+    (32, 320, 67, 7, 7, 0, False, 0),
+])
+def test_conv1x1_bwd_data(L, Co, Ci, G, oTo, oTi, ooff, use_mask, beta):
+    P = G * (oTo if oTo else 1)
+    P_in = G * (oTi if oTo else 1)
+    dout = rand(7, (P, Co))
+    W = rand(8, (Co, Ci)) / np.sqrt(Co)
+    full = dout @ W                                  # (P, Ci)
+    mask = rand(9, (P_in, Ci)) if use_mask else None
+    din0 = rand(10, (P_in, Ci))
+    ref = din0.clone() if beta else torch.zeros(P_in, Ci)
+    written = torch.zeros(P_in, dtype=torch.bool)
+    if oTo:
+        for t in range(oTo):
+            tt = t + ooff
+            if 0 <= tt < oTi:
+                ref[tt::oTi] = (ref[tt::oTi] if beta else 0) + full[t::oTo]
+                written[tt::oTi] = True
+    else:
+        ref = (ref if beta else 0) + full
+        written[:] = True
+    if use_mask:
+        ref = ref * (mask > 0)
+    din = dev(din0.clone())
+    L.call('mo_conv1x1_bwd_data', L.ptr(dev(dout)), Co, P, L.ptr(dev(W)), Ci, L.ptr(din), oTo, oTi, ooff,
+           L.ptr(dev(mask)) if use_mask else None, beta, L.stream())
+    got = din.cpu()
+    close(got[written], ref[written], what='din')
+    assert torch.equal(got[~written], din0[~written])      # rows without image untouched
+
+
+@pytest.mark.parametrize('N,R', [(20, 10), (67, 10), (300, 10)])
+def test_adp_fwd_bwd(L, N, R):
+    E1 = rand(11, (N, R)).requires_grad_(True)
+    E2 = rand(12, (R, N)).requires_grad_(True)
+    adp_ref = F.softmax(F.relu(E1 @ E2), dim=1)
+    adp = torch.empty(N, N, device='cuda')
+    adpT = torch.empty(N, N, device='cuda')
+    L.call('mo_adp_fwd', L.ptr(dev(E1.detach())), L.ptr(dev(E2.detach())), N, R, L.ptr(adp), L.ptr(adpT), L.stream())
+    close(adp, adp_ref, 1e-5, 'adp')
+    assert torch.equal(adpT.cpu(), adp.cpu().t())
+    dA = rand(13, (N, N))
+    adp_ref.backward(dA)
+    dAd = dev(dA.clone())
+    dE1 = torch.empty(N, R, device='cuda')
+    dE2 = torch.empty(R, N, device='cuda')
+    nz = (N + 127) // 128
+    ws = torch.empty(nz * R * N, device='cuda')
+    L.call('mo_adp_bwd', L.ptr(dev(E1.detach())), L.ptr(dev(E2.detach())), L.ptr(adp), L.ptr(dAd), N, R,
+           L.ptr(dE1), L.ptr(dE2), L.ptr(ws), ws.numel(), L.stream())
+    close(dE1, E1.grad, what='dE1')
+    close(dE2, E2.grad, what='dE2')
+
+
+@pytest.mark.parametrize('B,N,Tin,K,dil,affine', [(4, 20, 13, 2, 1, False), (4, 20, 12, 2, 2, True),
+                                                  (1, 67, 7, 1, 1, True), (3, 37, 9, 3, 2, True),
+                                                  (2, 50, 3, 2, 2, True)])
+def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine):
+    Tout = Tin - dil * (K - 1)
+    G = N * B
+    hprev = rand(20, (B, 32, N, Tin)).requires_grad_(True)
+    sc = (rand(21, (32,)) * 0.3 + 1.0) if affine else None
+    sh = rand(22, (32,)) * 0.3 if affine else None
+    Wf = (rand(23, (32, 32, 1, K)) / np.sqrt(32 * K)).requires_grad_(True)
+    Wg = (rand(24, (32, 32, 1, K)) / np.sqrt(32 * K)).requires_grad_(True)
+    bf = rand(25, (32,)).requires_grad_(True)
+    bg = rand(26, (32,)).requires_grad_(True)
+    u = hprev * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) if affine else hprev
+    g_ref = torch.tanh(F.conv2d(u, Wf, bf, dilation=(1, dil))) * torch.sigmoid(F.conv2d(u, Wg, bg, dilation=(1, dil)))
+    Wp = torch.empty(K * 64 * 32, device='cuda')
+    L.call('mo_tcn_pack_weights', L.ptr(dev(Wf.detach())), L.ptr(dev(Wg.detach())), K, L.ptr(Wp), L.stream())
+    hp = dev(nbtc(hprev.detach()))
+    g = torch.empty(G * Tout, 32, device='cuda')
+    scd, shd = (dev(sc), dev(sh)) if affine else (None, None)
+    L.call('mo_tcn_fwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
+           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(g), L.stream())
+    close(g, nbtc(g_ref), what='g')
+
+    dg = rand(27, tuple(g_ref.shape))
+    dres = rand(28, tuple(g_ref.shape))        # residual-path gradient, cropped add (graph_wavenet.py:247)
+    # reference: x = g + residual[..., -Tout:] ; gradient to u = conv^T(...) + pad(dres)
+    (g_ref * dg).sum().backward()
+    du_ref = hprev.grad.clone()
+    if affine:
+        # du is the gradient w.r.t. u (the BN output), not h_prev: undo the chain through the affine
+        du_ref = du_ref / sc.view(1, -1, 1, 1)
+    du_ref[..., Tin - Tout:] += dres
+    lib = L.load()
+    du = torch.empty(G * Tin, 32, device='cuda')
+    dWf = torch.empty(32, 32, 1, K, device='cuda'); dWg = torch.empty_like(dWf)
+    dbf = torch.empty(32, device='cuda'); dbg = torch.empty(32, device='cuda')
+    dpre = torch.empty(G * Tout, 64, device='cuda')
+    ws2 = torch.empty(lib.mo_wgrad_ws_floats(64, 32 * K, G * Tout), device='cuda')
+    L.call('mo_tcn_bwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
+           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(dev(nbtc(dg))), L.ptr(dev(nbtc(dres))), L.ptr(du),
+           L.ptr(dWf), L.ptr(dWg), L.ptr(dbf), L.ptr(dbg), L.ptr(dpre), L.ptr(ws2), L.stream())
+    close(du, nbtc(du_ref), what='du')
+    close(dWf, Wf.grad, what='dWf')
+    close(dWg, Wg.grad, what='dWg')
+    close(dbf, bf.grad, what='dbf')
+    close(dbg, bg.grad, what='dbg')
+
+
+@pytest.mark.parametrize('N,J', [(67, 7 * 32), (20, 4 * 12 * 32), (301, 2 * 3 * 32), (3000, 32)])
+def test_spmm_and_dense_products(L, N, J):
+    from multimodal_outage_amd.gwnet_engine import csr_from_dense
+    import scipy.sparse as sp
+    rs = np.random.RandomState(5)
+    A = (rs.uniform(size=(N, N)) < min(0.5, 6.0 / N)).astype(np.float32) * rs.uniform(0.1, 1, size=(N, N)).astype(np.float32)
+    # CSR indices bit-exact vs scipy (north star: adjacency indices bit-exact)
+    rp, ci, va = csr_from_dense(A.T)
+    c = sp.csr_matrix(A.T)
+    assert (rp == c.indptr).all() and (ci == c.indices).all() and (va == c.data).all()
+    X = rand(30, (N, J))
+    Y0 = rand(31, (N, J))
+    ref = torch.from_numpy(A).t() @ X
+    for beta in (0, 1):
+        Y = dev(Y0.clone())
+        L.call('mo_spmm_csr', L.ptr(dev(torch.from_numpy(rp))), L.ptr(dev(torch.from_numpy(ci))),
+               L.ptr(dev(torch.from_numpy(va))), N, L.ptr(dev(X)), L.ptr(Y), J, beta, L.stream())
+        close(Y, ref + (Y0 if beta else 0), what=f'spmm beta={beta}')
+    if N <= 400:
+        D = rand(32, (N, N)) / np.sqrt(N)
+        for beta in (0, 1):
+            Y = dev(Y0.clone())
+            L.call('mo_adj_gemm', L.ptr(dev(D)), N, L.ptr(dev(X)), L.ptr(Y), J, beta, L.stream())
+            close(Y, D.t() @ X + (Y0 if beta else 0), what=f'adj_gemm beta={beta}')
+        dY = rand(33, (N, J))
+        dA0 = rand(34, (N, N))
+        for beta in (0, 1):
+            dA = dev(dA0.clone())
+            L.call('mo_adj_grad', L.ptr(dev(X)), L.ptr(dev(dY)), N, J, L.ptr(dA), beta, L.stream())
+            close(dA, X @ dY.t() + (dA0 if beta else 0), what=f'adj_grad beta={beta}')
+
+
+def test_gemm_fragment_layout_asymmetric(L):
+    """A = I with an ASYMMETRIC B: catches a transposed MFMA C-write (guide section 3)."""
+    N, J = 128, 256
+    X = torch.arange(N * J, dtype=torch.float32).reshape(N, J) * 1e-3
+    I = torch.eye(N)
+    Y = torch.empty(N, J, device='cuda')
+    L.call('mo_adj_gemm', L.ptr(dev(I)), N, L.ptr(dev(X)), L.ptr(Y), J, 0, L.stream())
+    assert torch.equal(Y.cpu(), X)
+    P = torch.roll(torch.eye(N), 3, dims=1)   # asymmetric permutation: Y = P^T X
+    L.call('mo_adj_gemm', L.ptr(dev(P)), N, L.ptr(dev(X)), L.ptr(Y), J, 0, L.stream())
+    assert torch.equal(Y.cpu(), P.t() @ X)
+
+
+@pytest.mark.parametrize('B,N,Tin,Tout,ns,drop,affine', [(4, 20, 13, 12, 7, 0.0, False), (1, 67, 7, 7, 5, 0.0, True),
+                                                          (3, 37, 9, 7, 3, 0.0, True), (2, 20, 6, 4, 1, 0.0, True),
+                                                          (4, 50, 12, 10, 7, 0.3, True)])
+def test_gcn_mlp_bn(L, B, N, Tin, Tout, ns, drop, affine):
+    lib = L.load()
+    G = N * B
+    P = G * Tout
+    srcs = [rand(40 + s, (P, 32)) for s in range(ns)]
+    W = rand(50, (32, 32 * ns)) / np.sqrt(32 * ns)
+    b = rand(51, (32,))
+    res = rand(52, (G * Tin, 32))
+    sc = rand(53, (32,)) * 0.3 + 1.0 if affine else None
+    sh = rand(54, (32,)) * 0.3 if affine else None
+    cat = torch.cat(srcs, dim=1)
+    m = cat @ W.t() + b
+    resc = _rowmap(res, G, Tout, Tin, Tin - Tout)
+    if affine:
+        resc = resc * sc + sh
+    thresh = int(drop * 4294967296.0) if drop > 0 else 0
+    dscale = 1.0 / (1.0 - drop) if drop > 0 else 1.0
+    seed = 12345
+    h = torch.empty(P, 32, device='cuda')
+    partial = torch.empty(lib.mo_mlp_partial_floats(P), device='cuda')
+    sd = [dev(s) for s in srcs]
+    L.call('mo_gcn_mlp_fwd', L.ptr_array(sd), ns, L.ptr(dev(W)), L.ptr(dev(b)), G, Tout, Tin, L.ptr(dev(res)),
+           L.ptr(dev(sc)) if affine else None, L.ptr(dev(sh)) if affine else None, seed, thresh, dscale,
+           L.ptr(h), L.ptr(partial), L.stream())
+    hc = h.cpu()
+    if drop == 0.0:
+        href = m + resc
+        close(hc, href, what='h')
+        keep = torch.ones_like(m)
+    else:
+        # recover the mask from the output: elements are either resc (dropped) or m*dscale + resc
+        kept = m * dscale + resc
+        is_drop = (hc - resc).abs() < 1e-6 * (1 + resc.abs())
+        is_keep = (hc - kept).abs() < 1e-4 * (1 + kept.abs())
+        assert bool((is_drop | is_keep).all())
+        frac = float(is_drop.float().mean())
+        assert abs(frac - drop) < 0.02, frac
+        keep = (~is_drop).float() * dscale
+        href = hc
+    # BatchNorm finalize (training) vs nn.BatchNorm semantics
+    gamma = rand(55, (32,)) * 0.3 + 1.0
+    beta_ = rand(56, (32,)) * 0.3
+    rm0 = rand(57, (32,)) * 0.1
+    rv0 = rand(58, (32,)).abs() + 0.5
+    rm, rv = dev(rm0.clone()), dev(rv0.clone())
+    stats = torch.empty(4, 32, device='cuda')
+    nblk = (P + 127) // 128
+    L.call('mo_bn_finalize', L.ptr(partial), nblk, P, L.ptr(dev(gamma)), L.ptr(dev(beta_)), L.ptr(rm), L.ptr(rv),
+           0.1, 1e-5, 1, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
+    hx = href.t().reshape(1, 32, P, 1).clone().requires_grad_(True)
+    rmr, rvr = rm0.clone(), rv0.clone()
+    yref = F.batch_norm(hx, rmr, rvr, gamma, beta_, True, 0.1, 1e-5)
+    close(rm, rmr, 1e-5, 'running_mean')
+    close(rv, rvr, 1e-5, 'running_var')
+    ybn = hc * stats[0].cpu() + stats[1].cpu()
+    close(ybn, yref.detach().reshape(32, P).t(), what='bn out')
+    # eval-mode finalize
+    stats_e = torch.empty(4, 32, device='cuda')
+    L.call('mo_bn_finalize', None, 0, P, L.ptr(dev(gamma)), L.ptr(dev(beta_)), L.ptr(rm), L.ptr(rv),
+           0.1, 1e-5, 0, L.ptr(stats_e[0]), L.ptr(stats_e[1]), L.ptr(stats_e[2]), L.ptr(stats_e[3]), L.stream())
+    ye = F.batch_norm(hx.detach(), rmr, rvr, gamma, beta_, False, 0.1, 1e-5)
+    close(hc * stats_e[0].cpu() + stats_e[1].cpu(), ye.reshape(32, P).t(), what='bn eval')
+
+    # BN backward
+    dy = rand(59, (P, 32))
+    yref.backward(dy.t().reshape(1, 32, P, 1))
+    dh_ref = hx.grad.reshape(32, P).t()
+    dh = torch.empty(P, 32, device='cuda')
+    dgam = torch.empty(32, device='cuda'); dbet = torch.empty(32, device='cuda')
+    ws = torch.empty(lib.mo_mlp_partial_floats(P) + 64, device='cuda')
+    L.call('mo_bn_bwd', L.ptr(dev(dy)), L.ptr(h), P, L.ptr(dev(gamma)), L.ptr(stats[2]), L.ptr(stats[3]),
+           L.ptr(dh), L.ptr(dgam), L.ptr(dbet), L.ptr(ws), L.stream())
+    close(dh, dh_ref, what='bn dh')
+    xhat = (href - stats[2].cpu()) * stats[3].cpu()
+    close(dgam, (dy * xhat).sum(0), what='dgamma')
+    close(dbet, dy.sum(0), what='dbeta')
+
+    # mlp backward (with the regenerated dropout mask)
+    dhh = rand(60, (P, 32))
+    dm = dhh * keep
+    dcat = dm @ W
+    dsrcs = [torch.empty(P, 32, device='cuda') for _ in range(ns)]
+    dW = torch.empty(32, 32 * ns, device='cuda'); db = torch.empty(32, device='cuda')
+    wsm = torch.empty(lib.mo_wgrad_ws_floats(32, 32 * ns, P), device='cuda')
+    L.call('mo_gcn_mlp_bwd', L.ptr(dev(dhh)), L.ptr_array(sd), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P,
+           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), L.stream())
+    for s in range(ns):
+        close(dsrcs[s], dcat[:, 32 * s:32 * (s + 1)], what=f'dsrc{s}')
+    close(dW, dm.t() @ cat, what='dWm')
+    close(db, dm.sum(0), what='dbm')
+
+
+def test_metrics_and_grad(L):
+    lib = L.load()
+    n = 4 * 12 * 300 + 7
+    yh, y = rand(70, (n,)), rand(71, (n,))
+    y[:5] = 0.0
+    sums = torch.empty(4, device='cuda')
+    grad = torch.empty(n, device='cuda')
+    ws = torch.empty(lib.mo_metrics_ws_floats(n), device='cuda')
+    L.call('mo_mse_metrics', L.ptr(dev(yh)), L.ptr(dev(y)), n, L.ptr(sums), L.ptr(grad), L.ptr(ws), L.stream())
+    d = (yh - y).double()
+    s = sums.cpu().double()
+    assert abs(s[0] / n - (d * d).mean()) < 1e-5 * float((d * d).mean())
+    assert abs(s[1] / n - d.abs().mean()) < 1e-5
+    mape = (d.abs() / torch.clamp(y.double().abs(), min=1.17e-06)).mean()
+    assert abs(s[2] / n - mape) < 1e-4 * float(mape)
+    assert s[3] == n
+    close(grad, 2 * (yh - y) / n, 1e-5, 'dloss')
+
+
+def test_date2vec(L):
+    from helpers import golden
+    from oracle import params as P
+    G = golden('date2vec')
+    shapes = {'fc1': (32, 6), 'fc2': (32, 6), 'fc3': (32, 64), 'fc4': (6, 32), 'fc5': (6, 6)}
+    schema = {}
+    for k in [str(k) for k in G['keys']]:
+        mod, kind = k.split('.')
+        schema[k] = shapes[mod] if kind == 'weight' else (shapes[mod][0],)
+    v = P.seeded_values(schema, int(G['seed']))
+    x = torch.from_numpy(G['x'])
+    out = torch.empty(x.shape[0], 64, device='cuda')
+    L.call('mo_date2vec_encode', L.ptr(dev(x)), x.shape[0], L.ptr(dev(v['fc1.weight'])), L.ptr(dev(v['fc1.bias'])),
+           32, L.ptr(dev(v['fc2.weight'])), L.ptr(dev(v['fc2.bias'])), 32, L.ptr(out), L.stream())
+    # sin of arguments up to ~2000 rad: fp32 argument reduction limits absolute accuracy
+    assert_close(out.cpu(), G['y'], atol=2e-4, rtol=1e-4, what='date2vec golden')
+
+
+def test_adam_step(L):
+    n = 10007
+    p0, g, m0, v0 = rand(80, (n,)), rand(81, (n,)), rand(82, (n,)) * 0.1, rand(83, (n,)).abs() * 0.1
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pr.grad = g.clone()
+    opt.step()          # step 1 with zero state
+    p, m, v = dev(p0.clone()), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    L.call('mo_adam_step', L.ptr(p), L.ptr(dev(g)), L.ptr(m), L.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8,
+           1 - 0.9, 1 - 0.999, 1.0, L.stream())
+    close(p, pr.detach(), 1e-6, 'adam p')
