@@ -18,8 +18,22 @@ def L():
     return lib
 
 
+_keep = []
+
+
 def dev(t):
-    return t.contiguous().cuda()
+    """Device copy that stays alive until the end of the test (the C-ABI takes raw pointers, and a
+    temporary freed right after .data_ptr() would be recycled by the caching allocator)."""
+    d = t.contiguous().cuda()
+    _keep.append(d)
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    torch.cuda.synchronize()
+    _keep.clear()
 
 
 def nbtc(x):
