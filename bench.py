@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Headline benchmark: Graph-WaveNet training windows/s on BASELINE config 2
+(N=3000 nodes, C=32, T=12, kernel_size=2, 2 static CSR supports + dense adaptive adjacency).
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 default)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1, one rank per GPU)
+
+A step = forward + MSE loss + backward + gradient all-reduce (N>1, RCCL) + Adam, on a synthetic
+batch already resident in HBM.  Prints ONE JSON line (rank 0).  The roofline object is for the
+dominant kernel (the dense adaptive-adjacency node-axis product, MFMA bound), timed live with HIP
+events on the launching stream inside the timed region; the cpu_baseline object times the CPU oracle
+(oracle/, a port of the reference forward) on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_NODES, C_IN, T_IN, OUT_DIM, KSIZE = 3000, 32, 12, 12, 2
+# compulsory fp32 tensor traffic per window, forward; fwd+bwd counted as 3x
+ALG_BYTES_FWD_PER_WINDOW = 768.7e6
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def host_cores():
+    """Cores this process may really use: cgroup CPU quota if set, else affinity, capped at the
+    16-core share of a one-GPU box (oversubscribing the quota makes the CPU leg crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(supports, max_steps=3, batch=1, budget_s=25.0):
+    """The CPU oracle (a port of graph_wavenet.py:191-254: dense einsum supports, unfused ops) on the
+    host cores: fwd + MSE + bwd + Adam on batches of `batch` windows of the same workload; bounded
+    to about `budget_s` seconds of CPU work."""
+    from oracle import params as P
+    from oracle import gwnet_ref
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    schema = P.gwnet_schema(num_nodes=N_NODES, supports_len=3, in_dim=C_IN, out_dim=OUT_DIM, kernel_size=KSIZE)
+    p = P.as_param_dict(P.seeded_values(schema, 42))
+    leaves = [v for v in p.values() if v.requires_grad]
+    opt = torch.optim.Adam(leaves, lr=1e-3)
+    sup = [torch.from_numpy(s) for s in supports]
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(batch, C_IN, N_NODES, T_IN, generator=g)
+    y = torch.randn(batch, OUT_DIM, N_NODES, 1, generator=g)
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        out = gwnet_ref.gwnet_forward(p, x, supports=sup, kernel_size=KSIZE, dropout=0.3, training=True)
+        loss = F.mse_loss(out, y)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    t0 = time.perf_counter()
+    one()   # warm-up
+    warm = time.perf_counter() - t0
+    print(f'[bench] cpu_baseline warm-up step {warm:.1f} s on {cores} threads', file=sys.stderr, flush=True)
+    steps, t0 = 0, time.perf_counter()
+    while steps < max_steps and (steps == 0 or time.perf_counter() - t0 + warm < budget_s):
+        one()
+        steps += 1
+        print(f'[bench] cpu_baseline step {steps}: {time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 4), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} step(s) of fwd+MSE+bwd+Adam at batch {batch} (N=3000,T=12,C=32,K=2, "
+                      f"dropout 0.3) after 1 warm-up step; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='windows per GPU per step (weak scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = torch.device('cuda', local if world > 1 else 0)
+
+    import multimodal_outage_amd._lib as L
+    L.load()                      # the HIP extension is mandatory
+    from multimodal_outage_amd.models.graph_wavenet import gwnet
+    from multimodal_outage_amd.trainer import FlatTrainer
+    from multimodal_outage_amd import gwnet_engine as engine
+    from multimodal_outage_amd.graphs import knn_graph, asym_adj
+
+    A = knn_graph(N_NODES)
+    supports = [asym_adj(A), asym_adj(A.T)]
+    torch.manual_seed(42)         # lit.py:14
+    model = gwnet('cpu', num_nodes=N_NODES, dropout=0.3, supports=supports, in_dim=C_IN, out_dim=OUT_DIM,
+                  kernel_size=KSIZE, blocks=4, layers=2).to(dev).train()
+    trainer = FlatTrainer(model, lr=1e-3)
+    model._mo_grad_out = trainer.grad_out()
+    B = args.batch
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, C_IN, N_NODES, T_IN, generator=g).to(dev)
+    y = torch.randn(B, OUT_DIM, N_NODES, 1, generator=g).to(dev)
+    n_out = y.numel()
+    sums = torch.empty(4, device=dev)
+    dy = torch.empty_like(y)
+    ws = torch.empty(L.load().mo_metrics_ws_floats(n_out), device=dev)
+
+    def step():
+        out = model(x)
+        L.call('mo_mse_metrics', L.ptr(out), L.ptr(y), n_out, L.ptr(sums), L.ptr(dy), L.ptr(ws), L.stream())
+        out.backward(dy)
+        trainer.allreduce()
+        trainer.step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    engine.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, engine.PROFILE = engine.PROFILE, None
+    loss = float(sums[0].item()) / n_out
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    windows_per_s = world * B * args.steps / dt
+
+    # live roofline leg: HIP-event durations of every dense node-axis product in the timed region
+    gemm_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1) in prof)
+    gemm_flops = sum(f for (_, f, _, _) in prof)
+    n_launch = max(len(prof), 1)
+    ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "mo_gemm_kernel<128,128,16> dense adaptive-adjacency product "
+                                           "(mo_adj_gemm fwd/bwd-data + mo_adj_grad)",
+                "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "launches": len(prof), "avg_launch_ms": round(gemm_ms / n_launch, 4),
+                "avg_launch_gflop": round(gemm_flops / n_launch / 1e9, 3),
+                "traffic": None}
+    # secondary: everything that is not the dense product, priced against the HBM roofline with the
+    # compulsory-traffic model of SURVEY.md 8(d) (fp32, fwd+bwd = 3x forward)
+    step_ms = dt / args.steps * 1e3
+    rest_ms = max(step_ms - gemm_ms / args.steps, 1e-6)
+    alg_gb = 3 * ALG_BYTES_FWD_PER_WINDOW * B / 1e9
+    hbm_block = {"bound": "hbm", "what": "all non-GEMM kernels of the step (TCN gate, SpMM, mlp+BN, skip, head, "
+                                         "their backward), compulsory-traffic model",
+                 "algorithmic_GB_per_step": round(alg_gb, 3), "ms_per_step": round(rest_ms, 3),
+                 "achieved": round(alg_gb / (rest_ms * 1e-3), 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                 "frac": round(alg_gb / (rest_ms * 1e-3) / PEAK_HBM_GBPS, 4)}
+
+    line = {"metric": "train windows/sec (gwnet N=3k,T=12)", "value": round(windows_per_s, 3),
+            "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "gwnet fwd+MSE+bwd+Adam on (B,32,3000,12) graph windows, kernel_size=2, "
+                                   "blocks=4, layers=2, 2 static k-NN supports (CSR, nnz 17996 each) + dense "
+                                   "adaptive adjacency, dropout 0.3",
+                       "batch_per_gpu": B, "global_batch": B * world, "nodes": N_NODES, "seq_len": T_IN,
+                       "parallelism": f"dp{world}"},
+            "loss": round(loss, 6), "roofline": roofline, "roofline_hbm_block": hbm_block}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            print("[bench] gpu: " + json.dumps({k: line[k] for k in ("value", "ms_per_step", "loss")}), file=sys.stderr, flush=True)
+            line["cpu_baseline"] = cpu_baseline(supports, max_steps=args.cpu_steps)
+            line["speedup_vs_cpu"] = round(windows_per_s / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

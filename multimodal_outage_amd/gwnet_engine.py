@@ -52,6 +52,26 @@ class GwnetConfig:
         self.Cs, self.Ce = skip_channels, end_channels
         self.gcn, self.adaptive, self.dropout = gcn, adaptive, dropout
         self.names = names            # parameter order of the autograd Function
+        self.grad_out = None          # optional {name: preallocated grad tensor} (flat-buffer trainer)
+
+
+# Optional live kernel timing (bench.py roofline leg): when PROFILE is a list, every dense
+# node-axis product is bracketed by HIP events on the launching stream and appended as
+# (name, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
+def _dense(name, N, J, *args):
+    flops = 2.0 * N * N * J
+    if PROFILE is None:
+        L.call(name, *args)
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.call(name, *args)
+    e1.record()
+    PROFILE.append((name, flops, e0, e1))
 
 
 def _spmm(csr, n, X, Y, J, beta):
@@ -123,8 +143,8 @@ class GwnetFunction(torch.autograd.Function):
                 if cfg.adaptive:
                     x1 = _e(P, 32, dev)
                     x2 = _e(P, 32, dev)
-                    L.call('mo_adj_gemm', L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, st)
-                    L.call('mo_adj_gemm', L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, st)
+                    _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, st)
+                    _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, st)
                     srcs += [x1, x2]
                 W, bb = p[f'gconv.{i}.mlp.mlp.weight'], p[f'gconv.{i}.mlp.mlp.bias']
                 lt, ls, seed = thresh, dscale, (base_seed + 7919 * i) & 0xFFFFFFFF
@@ -173,6 +193,15 @@ class GwnetFunction(torch.autograd.Function):
         dev = dy.device
         st = L.stream()
         grads = {k: None for k in cfg.names}
+        gout = cfg.grad_out or {}
+
+        def gbuf(name, like=None, shape=None):
+            """Gradient destination: the trainer's flat-buffer view when registered, else a new tensor."""
+            t = gout.get(name)
+            if t is not None:
+                return t
+            return torch.empty_like(like) if like is not None else torch.empty(shape, device=dev,
+                                                                              dtype=torch.float32)
 
         def ws_for(M, Nn, P):
             return torch.empty(lib.mo_wgrad_ws_floats(M, Nn, P), device=dev, dtype=torch.float32)
@@ -184,13 +213,13 @@ class GwnetFunction(torch.autograd.Function):
         L.call('mo_nchw_to_nbtc', L.ptr(dy), L.ptr(dy_int), B, cfg.Cout, N, Tf, st)
         skip, r1 = ctx.skip, ctx.r1
         ws = ws_for(max(cfg.Ce, cfg.Cout), max(cfg.Ce, cfg.Cs), P_f)
-        gW2 = torch.empty_like(p['end_conv_2.weight']); gb2 = torch.empty_like(p['end_conv_2.bias'])
+        gW2 = gbuf('end_conv_2.weight', p['end_conv_2.weight']); gb2 = gbuf('end_conv_2.bias', p['end_conv_2.bias'])
         L.call('mo_conv1x1_bwd_weight', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(r1), cfg.Ce, 0, 0, 0, 0,
                L.ptr(gW2), L.ptr(gb2), L.ptr(ws), st)
         da1 = _e(P_f, cfg.Ce, dev)
         L.call('mo_conv1x1_bwd_data', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(p['end_conv_2.weight']), cfg.Ce,
                L.ptr(da1), 0, 0, 0, L.ptr(r1), 0, st)
-        gW1 = torch.empty_like(p['end_conv_1.weight']); gb1 = torch.empty_like(p['end_conv_1.bias'])
+        gW1 = gbuf('end_conv_1.weight', p['end_conv_1.weight']); gb1 = gbuf('end_conv_1.bias', p['end_conv_1.bias'])
         L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, P_f, L.ptr(skip), cfg.Cs, 0, 0, 0, 1,
                L.ptr(gW1), L.ptr(gb1), L.ptr(ws), st)
         dskip = _e(P_f, cfg.Cs, dev)
@@ -218,7 +247,7 @@ class GwnetFunction(torch.autograd.Function):
             if dxo is not None:
                 # BatchNorm backward (graph_wavenet.py:250)
                 dh = _e(P, 32, dev)
-                gg = torch.empty(32, device=dev); gb = torch.empty(32, device=dev)
+                gg = gbuf(f'bn.{i}.weight', shape=(32,)); gb = gbuf(f'bn.{i}.bias', shape=(32,))
                 wsb = torch.empty(lib.mo_mlp_partial_floats(P) + 64, device=dev, dtype=torch.float32)
                 L.call('mo_bn_bwd', L.ptr(dxo), L.ptr(ly['h']), P, L.ptr(p[f'bn.{i}.weight']),
                        L.ptr(ly['stats'][2]), L.ptr(ly['stats'][3]), L.ptr(dh), L.ptr(gg), L.ptr(gb),
@@ -232,7 +261,7 @@ class GwnetFunction(torch.autograd.Function):
                 else:
                     W = p[f'residual_convs.{i}.weight']
                     kW, kb = f'residual_convs.{i}.weight', f'residual_convs.{i}.bias'
-                gW = torch.empty_like(W); gbm = torch.empty(32, device=dev)
+                gW = gbuf(kW, W); gbm = gbuf(kb, shape=(32,))
                 wsm = ws_for(32, 32 * ns, P)
                 L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
                        ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), L.ptr(wsm), st)
@@ -248,12 +277,12 @@ class GwnetFunction(torch.autograd.Function):
                     if cfg.adaptive:
                         x1 = srcs[k]
                         dx1, dx2 = dsrcs[k], dsrcs[k + 1]
-                        L.call('mo_adj_gemm', L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, st)
-                        L.call('mo_adj_grad', L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
+                        _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, st)
+                        _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
                                1 if dAdp_started else 0, st)
                         dAdp_started = True
-                        L.call('mo_adj_gemm', L.ptr(ctx.adpT), N, L.ptr(dx1), L.ptr(dg), J, 1, st)
-                        L.call('mo_adj_grad', L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, st)
+                        _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx1), L.ptr(dg), J, 1, st)
+                        _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, st)
                 beta = 1
             else:
                 dg = torch.zeros((P, 32), device=dev, dtype=torch.float32)
@@ -262,15 +291,21 @@ class GwnetFunction(torch.autograd.Function):
             Ws = p[f'skip_convs.{i}.weight']
             L.call('mo_conv1x1_bwd_data', L.ptr(dskip), cfg.Cs, P_f, L.ptr(Ws), 32, L.ptr(dg), Tf, Tout,
                    Tout - Tf, None, beta, st)
-            gWs = torch.empty_like(Ws)
+            gWs = gbuf(f'skip_convs.{i}.weight', Ws)
             wss = ws_for(cfg.Cs, 32, P_f)
             L.call('mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
                    L.ptr(gWs), None, L.ptr(wss), st)
-            grads[f'skip_convs.{i}.weight'], grads[f'skip_convs.{i}.bias'] = gWs, dbs
+            grads[f'skip_convs.{i}.weight'] = gWs
+            sb = gout.get(f'skip_convs.{i}.bias')
+            if sb is not None:
+                sb.copy_(dbs)
+                grads[f'skip_convs.{i}.bias'] = sb
+            else:
+                grads[f'skip_convs.{i}.bias'] = dbs
             # gated TCN backward (graph_wavenet.py:222-226) + residual (:247)
             du = _e(G * Tin, 32, dev)
-            gWf = torch.empty_like(p[f'filter_convs.{i}.weight']); gWg = torch.empty_like(gWf)
-            gbf = torch.empty(32, device=dev); gbg = torch.empty(32, device=dev)
+            gWf = gbuf(f'filter_convs.{i}.weight', p[f'filter_convs.{i}.weight']); gWg = gbuf(f'gate_convs.{i}.weight', p[f'gate_convs.{i}.weight'])
+            gbf = gbuf(f'filter_convs.{i}.bias', shape=(32,)); gbg = gbuf(f'gate_convs.{i}.bias', shape=(32,))
             dpre = _e(P, 64, dev)
             ws2 = ws_for(64, 32 * K, P)
             L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
@@ -284,7 +319,7 @@ class GwnetFunction(torch.autograd.Function):
         # ---- start conv (graph_wavenet.py:191-196)
         pad = Tp - T
         Wst = p['start_conv.weight']
-        gWst = torch.empty_like(Wst); gbst = torch.empty(32, device=dev)
+        gWst = gbuf('start_conv.weight', Wst); gbst = gbuf('start_conv.bias', shape=(32,))
         wst = ws_for(32, cfg.Cin, G * Tp)
         L.call('mo_conv1x1_bwd_weight', L.ptr(dxo), 32, G * Tp, L.ptr(ctx.x_int), cfg.Cin, Tp, T, -pad, 0,
                L.ptr(gWst), L.ptr(gbst), L.ptr(wst), st)
@@ -302,7 +337,7 @@ class GwnetFunction(torch.autograd.Function):
             E1, E2 = p['nodevec1'], p['nodevec2']
             R = E1.shape[1]
             if dAdp_started:
-                gE1 = torch.empty_like(E1); gE2 = torch.empty_like(E2)
+                gE1 = gbuf('nodevec1', E1); gE2 = gbuf('nodevec2', E2)
                 nz = (N + 127) // 128
                 wsa = torch.empty(nz * R * N, device=dev, dtype=torch.float32)
                 L.call('mo_adp_bwd', L.ptr(E1), L.ptr(E2), L.ptr(ctx.adp), L.ptr(dAdp), N, R, L.ptr(gE1),
@@ -311,4 +346,6 @@ class GwnetFunction(torch.autograd.Function):
                 gE1 = torch.zeros_like(E1); gE2 = torch.zeros_like(E2)
             grads['nodevec1'], grads['nodevec2'] = gE1, gE2
 
-        return (None, None, None, None, dx) + tuple(grads[k] for k in cfg.names)
+        # gradients written straight into registered flat-buffer views are not handed to autograd
+        return (None, None, None, None, dx) + tuple(
+            None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)

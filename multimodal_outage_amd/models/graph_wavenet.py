@@ -222,6 +222,7 @@ class gwnet(nn.Module):
                           skip_channels=self.skip_channels, end_channels=self.end_channels,
                           gcn=self._use_gcn(), adaptive=self._use_gcn() and self.addaptadj,
                           dropout=self.dropout, names=names)
+        cfg.grad_out = getattr(self, '_mo_grad_out', None)
         bn_bufs = [(m.running_mean, m.running_var) for m in self.bn]
         if self.training:
             for m in self.bn:
