@@ -65,28 +65,47 @@ extern "C" long mo_wgrad_ws_floats(int M, int N, long P) {
   return (long)ns * M * N + 16;
 }
 
-// out[i] (=) sum_z slab[z][i]
+// out[i] (=) sum_z slab[z][i]: 32 outputs x 8 z-lanes per block, fixed summation order (deterministic)
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, long stride, int nz, float* __restrict__ out,
                                    long n) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float sm[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + tx;
   float s = 0.f;
-  for (int z = 0; z < nz; ++z) s += slab[(long)z * stride + i];
-  out[i] = s;
+  if (i < n)
+    for (int z = ty; z < nz; z += 8) s += slab[(long)z * stride + i];
+  sm[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sm[q][tx];
+    out[i] = t;
+  }
 }
+static inline dim3 slab_grid(long n) { return dim3(mo_cdiv(n, 32)); }
 
 // TCN weight-gradient unpack: slab[z][co'][tau*32+ci] -> dWf/dWg[co][ci][tau]
 __global__ void tcn_wgrad_reduce_kernel(const float* __restrict__ slab, long stride, int nz, int K,
                                         float* __restrict__ dWf, float* __restrict__ dWg) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 64 * 32K
-  int n = 64 * 32 * K;
-  if (i >= n) return;
+  __shared__ float sm[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + tx;  // over 64 * 32K
+  const int n = 64 * 32 * K;
   float s = 0.f;
-  for (int z = 0; z < nz; ++z) s += slab[(long)z * stride + i];
-  int cop = i / (32 * K), rem = i % (32 * K);
-  int tau = rem / 32, ci = rem % 32;
-  float* dst = (cop < 32) ? dWf : dWg;
-  dst[((cop & 31) * 32 + ci) * K + tau] = s;
+  if (i < n)
+    for (int z = ty; z < nz; z += 8) s += slab[(long)z * stride + i];
+  sm[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sm[q][tx];
+    int cop = i / (32 * K), rem = i % (32 * K);
+    int tau = rem / 32, ci = rem % 32;
+    float* dst = (cop < 32) ? dWf : dWg;
+    dst[((cop & 31) * 32 + ci) * K + tau] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -120,7 +139,7 @@ extern "C" int mo_colsum(const float* X, long P, int C, float* out, float* ws, v
   MO_CHECK_ARG(X && out && ws && P > 0 && C > 0);
   int nb = mo_cdiv(P, CS_ROWS);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, ST(stream), X, P, C, ws);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(mo_cdiv(C, 256)), dim3(256), 0, ST(stream), ws, (long)C, nb, out,
+  hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(C), dim3(256), 0, ST(stream), ws, (long)C, nb, out,
                      (long)C);
   return mo_launch_status();
 }
@@ -224,7 +243,7 @@ static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int
   if (rc) return rc;
   if (dW) {
     long n = (long)M * N;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, st, ws, n, nsplit, dW, n);
+    hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(n), dim3(256), 0, st, ws, n, nsplit, dW, n);
   }
   return mo_launch_status();
 }
@@ -365,7 +384,7 @@ extern "C" int mo_adp_bwd(const float* E1, const float* E2, const float* adp, fl
   hipLaunchKernelGGL(adp_bwd_rows_kernel, dim3(N), dim3(256), 0, ST(stream), E1, E2, adp, dA, N, R, dE1);
   hipLaunchKernelGGL(adp_bwd_cols_kernel, dim3(mo_cdiv(N, 256), nz), dim3(256), 0, ST(stream), E1, dA, N, R, ws);
   long n = (long)R * N;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), ws, n, nz, dE2, n);
+  hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(n), dim3(256), 0, ST(stream), ws, n, nz, dE2, n);
   return mo_launch_status();
 }
 
@@ -456,7 +475,7 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
     rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, st);
     if (rc) return rc;
     int nsplit, kchunk; wgrad_plan(64, 32 * K, Pout, nsplit, kchunk);
-    hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(mo_cdiv(64 * 32 * K, 256)), dim3(256), 0, st, ws2,
+    hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(mo_cdiv(64 * 32 * K, 32)), dim3(256), 0, st, ws2,
                        (long)64 * 32 * K, nsplit, K, dWf, dWg);
   }
   // 4) bias gradients: column sums of dpre (64 columns) -> [dbf | dbg] via ws2 (stream ordered)
