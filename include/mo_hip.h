@@ -123,6 +123,69 @@ long mo_colsum_ws_floats(long P, int C);
 int mo_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                  float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, void* stream);
 
+/* ==== UNet encoder/decoder conv stacks (unet.py:40-92, batched over all B*67*H tiles) ===============
+ * NCHW images; `istride`/`ostride` are image strides in floats (so channel slices of wider buffers can
+ * be addressed).  An "activated view" is a raw conv output y with the folded per-(group,channel)
+ * BatchNorm affine sc/sh [G][C] (+ReLU) applied on load; sc==NULL means a plain tensor.  Groups are
+ * `gsize` consecutive images: the reference calls each block once per county on `horizon` images, so
+ * train-mode BatchNorm statistics are per (batch element, county). */
+
+/* DoubleConv conv (unet.py:44,47; nn.Conv2d k=3 pad=1 bias=False) over the channel concat of up to two
+ * activated views (the skip/up cat of unet.py:83): out[img][co] raw. W: (Co, C0+C1, 3, 3). */
+int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, const float* sh0, int relu0,
+                   const float* in1, int C1, long istride1, const float* sc1, const float* sh1, int relu1,
+                   int gsize, const float* W, int Co, long n_img, int H, int Wd, float* out, long ostride,
+                   void* stream);
+/* Wf[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]; the data gradient is mo_conv3x3_fwd(dy, Wf). */
+int mo_conv3x3_flip_weights(const float* W, int Co, int Ci, float* Wf, void* stream);
+long mo_unet_wgrad_ws_floats(int M, int N, long P);
+/* dW[co][ci][tap] = sum_{img,pix} dy * act(in) shifted; ws: mo_unet_wgrad_ws_floats(Co,(C0+C1)*9,n_img*H*W) */
+int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, const float* in0, int C0, long istride0,
+                          const float* sc0, const float* sh0, int relu0, const float* in1, int C1,
+                          long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
+                          long n_img, int H, int Wd, float* dW, float* ws, void* stream);
+/* OutConv (unet.py:86-92): 1x1 conv with bias on an activated NCHW view */
+int mo_nchw_conv1x1_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
+                        int gsize, const float* W, const float* b, int Co, long n_img, int HW, float* out,
+                        long ostride, void* stream);
+int mo_nchw_conv1x1_bwd_data(const float* dout, long dostride, int Co, const float* W, int Ci, long n_img,
+                             int HW, float* din, long distride, void* stream);
+int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride,
+                               int Ci, const float* sc, const float* sh, int relu, int gsize, long n_img,
+                               int HW, float* dW, float* ws, void* stream);
+/* Up.up (unet.py:71): ConvTranspose2d(Ci, Co, k=2, s=2) with bias; W (Ci, Co, 2, 2); H,Wd = input size */
+int mo_convt2x2_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
+                    int gsize, const float* W, const float* b, int Co, long n_img, int H, int Wd, float* out,
+                    long ostride, void* stream);
+int mo_convt2x2_bwd_data(const float* dout, long dostride, int Co, const float* W, int Ci, long n_img, int H,
+                         int Wd, float* din, long distride, void* stream);
+int mo_convt2x2_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride, int Ci,
+                           const float* sc, const float* sh, int relu, int gsize, long n_img, int H, int Wd,
+                           float* dW, float* ws, void* stream);
+/* BatchNorm2d statistics (unet.py:45,48): stats[img][c] = (sum, sumsq) over HW */
+int mo_nchw_stats(const float* y, long istride, int C, long n_img, int HW, float* stats, void* stream);
+/* per-group finalize: scale/shift/mean/rstd [G][C]; running stats receive G sequential momentum updates
+ * in group order (= the reference's county-then-batch order of nn.BatchNorm2d calls) */
+int mo_group_bn_finalize(const float* stats, long n_img, int C, int gsize, int HW, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum,
+                         float eps, int training, float* scale, float* shift, float* mean, float* rstd,
+                         void* stream);
+/* materialise relu(y*sc+sh), optionally 2x2 max-pooled (Down, unet.py:60) */
+int mo_unet_act(const float* y, long istride, int C, long n_img, int H, int Wd, const float* sc,
+                const float* sh, int gsize, int pool, float* out, long ostride, void* stream);
+/* backward through ReLU + group BatchNorm (+ max-pool routing of dp); da = gradient w.r.t. the activated
+ * view, dp = gradient w.r.t. its pooled version (either may be NULL); ws: mo_unet_act_bwd_ws_floats */
+long mo_unet_act_bwd_ws_floats(long n_img, int C);
+int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
+                    const float* gamma, const float* mean, const float* rstd, const float* sc,
+                    const float* sh, const float* da, long dastride, const float* dp, long dpstride,
+                    float* dy, long dystride, float* dgamma, float* dbeta, float* ws, void* stream);
+/* out[c] = sum over images and pixels (bias gradients); ws: n_img*C*2 floats */
+int mo_nchw_channel_sum(const float* x, long istride, int C, long n_img, int HW, float* out, float* ws,
+                        void* stream);
+/* nn.Dropout (unet.py:135,159) with the counter-based mask; the same call is its own backward */
+int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint32_t thresh, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,7 +41,8 @@ static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M
   if (M <= 0 || N <= 0) return MO_OK;
   dim3 grid(mo_cdiv(M, BM), mo_cdiv(N, BN), nz);
   dim3 block(WM * WN * 64);
-  hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI>), grid, block, 0, st, A, B, E);
+  MoGeom G = {0, 0, 0, 1, 0, 0};
+  hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI>), grid, block, 0, st, A, B, E, G);
   return mo_launch_status();
 }
 

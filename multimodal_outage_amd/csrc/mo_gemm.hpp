@@ -42,7 +42,23 @@ struct MoOperand {
   int cols;   // logical extent along the column direction
 };
 
-enum { MO_EPI_STORE = 0, MO_EPI_GATE = 1, MO_EPI_GATE_BWD = 2, MO_EPI_MLP = 3 };
+enum { MO_EPI_STORE = 0, MO_EPI_GATE = 1, MO_EPI_GATE_BWD = 2, MO_EPI_MLP = 3, MO_EPI_NCHW = 4, MO_EPI_CONVT = 5 };
+
+// Source kinds of an operand (what (row, col) of the virtual matrix means):
+//   PLAIN : row-major segments as described by MoSeg (channels-last activations, weights)
+//   IM2COL: rows q=(ci,tap) of a 3x3/pad-1 im2col matrix over NCHW images, cols p=(img,y,x);
+//           up to two channel segments (the skip/up concat of unet.py:83) with a per-(group,channel)
+//           folded BatchNorm affine + ReLU applied on load (seg.ld = image stride in floats)
+//   NCHW  : rows = channel, cols p=(img,pix) of an NCHW tensor (same on-load activation)
+//   CONVT : rows r=(co,ky,kx), cols p=(img,y,x) of the 2x up-sampled NCHW tensor gathered at
+//           (2y+ky, 2x+kx)  (ConvTranspose2d k=2,s=2 backward, unet.py:71)
+enum { MO_SRC_PLAIN = 0, MO_SRC_IM2COL = 1, MO_SRC_NCHW = 2, MO_SRC_CONVT = 3 };
+
+struct MoGeom {
+  int H, W, HW;     // spatial size of the (low-resolution, for CONVT) pixel grid
+  int gsize;        // images per BatchNorm group (the reference normalises per county call: `horizon` images)
+  int C0, C1;       // channels of segment 0 / 1
+};
 
 struct MoEpi {
   float* out[MO_MAX_SEG];  // outputs, segmented along n when nout>1 (n -> out[n/osegw][.., n%osegw])
@@ -115,7 +131,77 @@ __device__ __forceinline__ float4 mo_fetch4(const MoSeg* segs, int nseg, int seg
   return v;
 }
 
-template <int BX, int BK, int NT, int MODE>
+__device__ __forceinline__ float4 mo_fetch4_im2col(const MoSeg* segs, const MoGeom& g, int rows, int cols, int q,
+                                                   int p) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q >= rows || p >= cols) return v;
+  const int ci = q / 9, tap = q - ci * 9;
+  const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
+  const int s = (ci >= g.C0) ? 1 : 0;
+  const int c = ci - (s ? g.C0 : 0);
+  const int Cs = s ? g.C1 : g.C0;
+  const MoSeg& sg = segs[s];
+  const int img = p / g.HW, pix = p - img * g.HW;
+  const int y = pix / g.W, x = pix - y * g.W;
+  const int yy = y + ky;
+  if (yy < 0 || yy >= g.H) return v;
+  const float* base = sg.ptr + (long)img * sg.ld + (long)c * g.HW + yy * g.W;
+  float sc = 1.f, sh = 0.f;
+  const bool aff = sg.scale != nullptr;
+  if (aff) { const int grp = img / g.gsize; sc = sg.scale[grp * Cs + c]; sh = sg.shift[grp * Cs + c]; }
+  float* vp = &v.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int xx = x + j + kx;
+    if (xx >= 0 && xx < g.W) {
+      float t = base[xx];
+      if (aff) t = t * sc + sh;
+      if (sg.relu) t = fmaxf(t, 0.f);
+      vp[j] = t;
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ float4 mo_fetch4_nchw(const MoSeg* segs, const MoGeom& g, int rows, int cols, int c,
+                                                 int p) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c >= rows || p >= cols) return v;
+  const MoSeg& sg = segs[0];
+  const int img = p / g.HW, pix = p - img * g.HW;
+  v = *reinterpret_cast<const float4*>(sg.ptr + (long)img * sg.ld + (long)c * g.HW + pix);
+  if (sg.scale) {
+    const int grp = img / g.gsize;
+    const float sc = sg.scale[grp * g.C0 + c], sh = sg.shift[grp * g.C0 + c];
+    v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+  }
+  if (sg.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  return v;
+}
+
+__device__ __forceinline__ float4 mo_fetch4_convt(const MoSeg* segs, const MoGeom& g, int rows, int cols, int r,
+                                                  int p) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r >= rows || p >= cols) return v;
+  const MoSeg& sg = segs[0];
+  const int co = r >> 2, ky = (r >> 1) & 1, kx = r & 1;
+  const int img = p / g.HW, pix = p - img * g.HW;
+  const int y = pix / g.W, x = pix - y * g.W;
+  const float* base = sg.ptr + (long)img * sg.ld + (long)co * 4 * g.HW + (long)(2 * y + ky) * 2 * g.W + 2 * x + kx;
+  v.x = base[0]; v.y = base[2]; v.z = base[4]; v.w = base[6];
+  return v;
+}
+
+template <int SRC>
+__device__ __forceinline__ float4 mo_fetch(const MoSeg* segs, int nseg, int segw, int rows, int cols,
+                                           const MoGeom& g, int r, int c) {
+  if (SRC == MO_SRC_IM2COL) return mo_fetch4_im2col(segs, g, rows, cols, r, c);
+  if (SRC == MO_SRC_NCHW) return mo_fetch4_nchw(segs, g, rows, cols, r, c);
+  if (SRC == MO_SRC_CONVT) return mo_fetch4_convt(segs, g, rows, cols, r, c);
+  return mo_fetch4(segs, nseg, segw, rows, cols, r, c);
+}
+
+template <int BX, int BK, int NT, int MODE, int SRC = MO_SRC_PLAIN>
 struct MoTile {
   static constexpr int PAD = (MODE == MO_KROWS) ? 4 : 1;
   static constexpr int LD = BX + PAD;
@@ -123,16 +209,16 @@ struct MoTile {
   static_assert((BK * BX / 4) % NT == 0, "tile/thread mismatch");
 
   __device__ __forceinline__ static void load(float4 (&reg)[NV], const MoSeg* segs, int nseg, int segw,
-                                              int rows, int cols, int x0, int k0, int tid) {
+                                              int rows, int cols, const MoGeom& g, int x0, int k0, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int f = tid + i * NT;
       if (MODE == MO_KROWS) {
         int k = f / (BX / 4), x4 = f % (BX / 4);
-        reg[i] = mo_fetch4(segs, nseg, segw, rows, cols, k0 + k, x0 + 4 * x4);
+        reg[i] = mo_fetch<SRC>(segs, nseg, segw, rows, cols, g, k0 + k, x0 + 4 * x4);
       } else {
         int x = f / (BK / 4), k4 = f % (BK / 4);
-        reg[i] = mo_fetch4(segs, nseg, segw, rows, cols, x0 + x, k0 + 4 * k4);
+        reg[i] = mo_fetch<SRC>(segs, nseg, segw, rows, cols, g, x0 + x, k0 + 4 * k4);
       }
     }
   }
@@ -156,15 +242,16 @@ struct MoTile {
 
 __device__ __forceinline__ float mo_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI>
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI, int ASRC = MO_SRC_PLAIN,
+          int BSRC = MO_SRC_PLAIN>
 __global__ void __launch_bounds__(WM* WN * 64)
-mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E) {
+mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom G) {
   constexpr int NT = WM * WN * 64;
   constexpr int SM = BM / WM, SN = BN / WN;
   constexpr int TM = SM / 32, TN = SN / 32;
   static_assert(SM % 32 == 0 && SN % 32 == 0, "wave tile must be a multiple of 32x32");
-  using TA = MoTile<BM, BK, NT, AMODE>;
-  using TB = MoTile<BN, BK, NT, BMODE>;
+  using TA = MoTile<BM, BK, NT, AMODE, ASRC>;
+  using TB = MoTile<BN, BK, NT, BMODE, BSRC>;
 
   __shared__ __attribute__((aligned(16))) float As[2][BK * TA::LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * TB::LD];
@@ -206,8 +293,8 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E) {
   // Bound the k direction by kend as well (split-K chunks end on BK multiples except the last,
   // which ends at K == rows/cols, so the operand's own extent check is sufficient).
   if (nk > 0) {
-    TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, m0, kbeg, tid);
-    TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, n0, kbeg, tid);
+    TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, G, m0, kbeg, tid);
+    TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, G, n0, kbeg, tid);
     TA::store(ra, As[0], tid);
     TB::store(rb, Bs[0], tid);
   }
@@ -217,8 +304,8 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, m0, kbeg + (kt + 1) * BK, tid);
-      TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, n0, kbeg + (kt + 1) * BK, tid);
+      TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, G, m0, kbeg + (kt + 1) * BK, tid);
+      TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, G, n0, kbeg + (kt + 1) * BK, tid);
     }
     const float* Ac = As[cur];
     const float* Bc = Bs[cur];
@@ -305,6 +392,36 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E) {
           const float dg = E.aux[(long)m * E.ldaux + c];
           E.out[0][(long)m * E.ldo + c] = dg * g * (1.f - f * f);
           E.out[0][(long)m * E.ldo + 32 + c] = dg * f * g * (1.f - g);
+        }
+      }
+    }
+  } else if (EPI == MO_EPI_NCHW || EPI == MO_EPI_CONVT) {
+    // rows m = channel (or (co,ky,kx) for CONVT), cols n = pixel p=(img,y,x): NCHW store, coalesced along n
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int pcol = n0 + wn0 + j * 32 + fi;
+      if (pcol >= N) continue;
+      const int img = pcol / G.HW, pix = pcol - img * G.HW;
+      float* obase = E.out[0] + (long)img * E.ldo;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+          if (m >= M) continue;
+          float v = acc[i][j][r];
+          if (EPI == MO_EPI_NCHW) {
+            if (E.bias) v += E.bias[m];
+            if (E.relu) v = fmaxf(v, 0.f);
+            float* o = obase + (long)(E.ooff + m) * G.HW + pix;
+            if (E.beta) v += *o;
+            *o = v;
+          } else {
+            const int co = m >> 2, ky = (m >> 1) & 1, kx = m & 1;
+            const int y = pix / G.W, x = pix - y * G.W;
+            if (E.bias) v += E.bias[co];
+            obase[(long)(E.ooff + co) * 4 * G.HW + (long)(2 * y + ky) * 2 * G.W + 2 * x + kx] = v;
+          }
         }
       }
     }

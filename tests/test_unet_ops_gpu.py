@@ -1,0 +1,190 @@
+"""GPU parity tests for the UNet C-ABI ops (unet.py:40-92) against plain fp32 torch on CPU; 1e-4."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rand
+from test_ops_gpu import dev, close, _release, L  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def act_view(y, sc, sh, gsize):
+    """relu(y*sc+sh) with per-(group,channel) affine; y (n,C,H,W), sc/sh (G,C)."""
+    n, C = y.shape[:2]
+    s = sc.repeat_interleave(gsize, 0).view(n, C, 1, 1)
+    t = sh.repeat_interleave(gsize, 0).view(n, C, 1, 1)
+    return F.relu(y * s + t)
+
+
+@pytest.mark.parametrize('n,gs,C0,C1,Co,H,W', [(6, 3, 1, 0, 4, 16, 16), (4, 2, 8, 0, 8, 8, 12), (4, 2, 16, 16, 16, 8, 8),
+                                                (2, 1, 64, 0, 64, 8, 8), (3, 3, 4, 4, 4, 32, 32), (2, 2, 32, 32, 32, 16, 16)])
+def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W):
+    lib = L.load()
+    G = n // gs
+    x0 = rand(1, (n, C0, H, W)).requires_grad_(True)
+    sc0, sh0 = rand(2, (G, C0)) * 0.3 + 1, rand(3, (G, C0)) * 0.3
+    a0 = act_view(x0, sc0, sh0, gs)
+    ins = [a0]
+    if C1:
+        x1 = rand(4, (n, C1, H, W)).requires_grad_(True)
+        ins.append(x1)
+    Wt = (rand(5, (Co, C0 + C1, 3, 3)) / np.sqrt(9 * (C0 + C1))).requires_grad_(True)
+    ref = F.conv2d(torch.cat(ins, 1), Wt, None, padding=1)
+    out = torch.empty(n, Co, H, W, device='cuda')
+    x0d = dev(x0.detach())
+    x1d = dev(x1.detach()) if C1 else None
+    args_in = (L.ptr(x0d), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1,
+               L.ptr(x1d), C1, C1 * H * W, None, None, 0)
+    L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(dev(Wt.detach())), Co, n, H, W, L.ptr(out), Co * H * W, L.stream())
+    close(out, ref, what='conv fwd')
+    dy = rand(6, tuple(ref.shape))
+    ref.backward(dy)
+    # data gradient = conv of dy with the flipped/transposed weights -> gradient w.r.t. the *activated* cat
+    Ci = C0 + C1
+    Wf = torch.empty(Ci, Co, 3, 3, device='cuda')
+    L.call('mo_conv3x3_flip_weights', L.ptr(dev(Wt.detach())), Co, Ci, L.ptr(Wf), L.stream())
+    dcat = torch.empty(n, Ci, H, W, device='cuda')
+    L.call('mo_conv3x3_fwd', L.ptr(dev(dy)), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wf), Ci,
+           n, H, W, L.ptr(dcat), Ci * H * W, L.stream())
+    dcat_ref = F.conv_transpose2d(dy, Wt.detach(), padding=1)
+    close(dcat, dcat_ref, what='conv bwd data')
+    if C1:
+        close(dcat[:, C0:], x1.grad, what='dx1')
+    dW = torch.empty(Co, Ci, 3, 3, device='cuda')
+    ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * H * W), device='cuda')
+    L.call('mo_conv3x3_bwd_weight', L.ptr(dev(dy)), Co * H * W, Co, *args_in, gs, n, H, W, L.ptr(dW), L.ptr(ws), L.stream())
+    close(dW, Wt.grad, what='conv dW')
+
+
+@pytest.mark.parametrize('n,gs,C,H,W,pool,use_da', [(6, 3, 4, 16, 16, True, True), (4, 2, 8, 8, 8, True, False),
+                                                    (4, 1, 16, 8, 12, False, True), (2, 2, 64, 8, 8, False, True)])
+def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da):
+    """[conv out] -> BatchNorm2d (train, per group of gs images) -> ReLU (-> MaxPool2d(2)) and backward."""
+    lib = L.load()
+    G = n // gs
+    y = rand(10, (n, C, H, W)).requires_grad_(True)
+    gamma = (rand(11, (C,)) * 0.3 + 1).requires_grad_(True)
+    beta = (rand(12, (C,)) * 0.3).requires_grad_(True)
+    rm0, rv0 = rand(13, (C,)) * 0.1, rand(14, (C,)).abs() + 0.5
+    rm, rv = rm0.clone(), rv0.clone()
+    acts = []
+    for g in range(G):                                   # reference: one BN call per group, in order
+        acts.append(F.relu(F.batch_norm(y[g * gs:(g + 1) * gs], rm, rv, gamma, beta, True, 0.1, 1e-5)))
+    a = torch.cat(acts, 0)
+    yd = dev(y.detach())
+    stats = torch.empty(n, C, 2, device='cuda')
+    L.call('mo_nchw_stats', L.ptr(yd), C * H * W, C, n, H * W, L.ptr(stats), L.stream())
+    rmd, rvd = dev(rm0.clone()), dev(rv0.clone())
+    aff = torch.empty(4, G, C, device='cuda')
+    gd, bd = dev(gamma.detach()), dev(beta.detach())
+    L.call('mo_group_bn_finalize', L.ptr(stats), n, C, gs, H * W, L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), 0.1, 1e-5, 1,
+           L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(aff[2]), L.ptr(aff[3]), L.stream())
+    close(rmd, rm, 1e-5, 'running_mean (sequential group updates)')
+    close(rvd, rv, 1e-5, 'running_var')
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.empty(n, C, Ho, Wo, device='cuda')
+    L.call('mo_unet_act', L.ptr(yd), C * H * W, C, n, H, W, L.ptr(aff[0]), L.ptr(aff[1]), gs, 1 if pool else 0,
+           L.ptr(out), C * Ho * Wo, L.stream())
+    ref_out = F.max_pool2d(a, 2) if pool else a
+    close(out, ref_out, what='act/pool')
+    # backward: loss = <a, da> + <pool(a), dp>
+    da = rand(15, (n, C, H, W)) if use_da else None
+    dp = rand(16, (n, C, H // 2, W // 2)) if pool else None
+    loss = 0
+    if use_da:
+        loss = loss + (a * da).sum()
+    if pool:
+        loss = loss + (F.max_pool2d(a, 2) * dp).sum()
+    loss.backward()
+    dy = torch.empty(n, C, H, W, device='cuda')
+    dgam = torch.empty(C, device='cuda'); dbet = torch.empty(C, device='cuda')
+    ws = torch.empty(lib.mo_unet_act_bwd_ws_floats(n, C), device='cuda')
+    L.call('mo_unet_act_bwd', L.ptr(yd), C * H * W, C, n, H, W, gs, L.ptr(gd), L.ptr(aff[2]), L.ptr(aff[3]),
+           L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(dev(da)) if use_da else None, C * H * W,
+           L.ptr(dev(dp)) if pool else None, C * (H // 2) * (W // 2), L.ptr(dy), C * H * W, L.ptr(dgam), L.ptr(dbet),
+           L.ptr(ws), L.stream())
+    close(dy, y.grad, what='dy')
+    close(dgam, gamma.grad, what='dgamma')
+    close(dbet, beta.grad, what='dbeta')
+
+
+@pytest.mark.parametrize('n,gs,Ci,Co,H,W,act', [(4, 2, 64, 32, 8, 8, False), (4, 2, 8, 4, 16, 16, True), (2, 1, 16, 8, 4, 8, True)])
+def test_convt2x2_fwd_bwd(L, n, gs, Ci, Co, H, W, act):
+    lib = L.load()
+    G = n // gs
+    x = rand(20, (n, Ci, H, W)).requires_grad_(True)
+    sc, sh = rand(21, (G, Ci)) * 0.3 + 1, rand(22, (G, Ci)) * 0.3
+    a = act_view(x, sc, sh, gs) if act else x
+    a.retain_grad()
+    Wt = (rand(23, (Ci, Co, 2, 2)) / np.sqrt(Ci)).requires_grad_(True)
+    b = rand(24, (Co,)).requires_grad_(True)
+    ref = F.conv_transpose2d(a, Wt, b, stride=2)
+    xd = dev(x.detach())
+    scd, shd = (dev(sc), dev(sh)) if act else (None, None)
+    out = torch.empty(n, Co, 2 * H, 2 * W, device='cuda')
+    L.call('mo_convt2x2_fwd', L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd), 1 if act else 0, gs,
+           L.ptr(dev(Wt.detach())), L.ptr(dev(b.detach())), Co, n, H, W, L.ptr(out), Co * 4 * H * W, L.stream())
+    close(out, ref, what='convT fwd')
+    dout = rand(25, tuple(ref.shape))
+    ref.backward(dout)
+    dd = dev(dout)
+    din = torch.empty(n, Ci, H, W, device='cuda')
+    L.call('mo_convt2x2_bwd_data', L.ptr(dd), Co * 4 * H * W, Co, L.ptr(dev(Wt.detach())), Ci, n, H, W, L.ptr(din),
+           Ci * H * W, L.stream())
+    close(din, a.grad, what='convT bwd data')
+    dW = torch.empty(Ci, Co, 2, 2, device='cuda')
+    ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Ci, 4 * Co, n * H * W), device='cuda')
+    L.call('mo_convt2x2_bwd_weight', L.ptr(dd), Co * 4 * H * W, Co, L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd),
+           1 if act else 0, gs, n, H, W, L.ptr(dW), L.ptr(ws), L.stream())
+    close(dW, Wt.grad, what='convT dW')
+    db = torch.empty(Co, device='cuda')
+    ws2 = torch.empty(n * Co * 2, device='cuda')
+    L.call('mo_nchw_channel_sum', L.ptr(dd), Co * 4 * H * W, Co, n, 4 * H * W, L.ptr(db), L.ptr(ws2), L.stream())
+    close(db, b.grad, what='convT db')
+
+
+@pytest.mark.parametrize('n,gs,Ci,Co,HW', [(4, 2, 4, 1, 256), (2, 1, 4, 3, 64)])
+def test_outconv_fwd_bwd(L, n, gs, Ci, Co, HW):
+    lib = L.load()
+    G = n // gs
+    x = rand(30, (n, Ci, HW, 1)).requires_grad_(True)
+    sc, sh = rand(31, (G, Ci)) * 0.3 + 1, rand(32, (G, Ci)) * 0.3
+    a = act_view(x, sc, sh, gs)
+    a.retain_grad()
+    Wt = rand(33, (Co, Ci, 1, 1)).requires_grad_(True)
+    b = rand(34, (Co,)).requires_grad_(True)
+    ref = F.conv2d(a, Wt, b)
+    xd, scd, shd = dev(x.detach()), dev(sc), dev(sh)
+    out = torch.empty(n, Co, HW, device='cuda')
+    L.call('mo_nchw_conv1x1_fwd', L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, L.ptr(dev(Wt.detach())),
+           L.ptr(dev(b.detach())), Co, n, HW, L.ptr(out), Co * HW, L.stream())
+    close(out, ref.reshape(n, Co, HW), what='outc fwd')
+    dout = rand(35, tuple(ref.shape))
+    ref.backward(dout)
+    dd = dev(dout)
+    din = torch.empty(n, Ci, HW, device='cuda')
+    L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dd), Co * HW, Co, L.ptr(dev(Wt.detach())), Ci, n, HW, L.ptr(din), Ci * HW,
+           L.stream())
+    close(din, a.grad.reshape(n, Ci, HW), what='outc bwd data')
+    dW = torch.empty(Co, Ci, device='cuda')
+    ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci, n * HW), device='cuda')
+    L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dd), Co * HW, Co, L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, n,
+           HW, L.ptr(dW), L.ptr(ws), L.stream())
+    close(dW, Wt.grad.reshape(Co, Ci), what='outc dW')
+
+
+def test_dropout_mask(L):
+    n = 100003
+    x = rand(40, (n,))
+    y = torch.empty(n, device='cuda')
+    thresh = int(0.3 * 4294967296.0)
+    L.call('mo_dropout', L.ptr(dev(x)), L.ptr(y), n, 77, thresh, 1.0 / 0.7, L.stream())
+    yc = y.cpu()
+    kept = yc != 0
+    assert abs(float(kept.float().mean()) - 0.7) < 0.01
+    assert torch.allclose(yc[kept], x[kept] / 0.7, rtol=1e-6)
+    y2 = torch.empty(n, device='cuda')
+    L.call('mo_dropout', L.ptr(dev(x)), L.ptr(y2), n, 77, thresh, 1.0 / 0.7, L.stream())
+    assert torch.equal(y, y2)
