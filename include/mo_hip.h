@@ -185,6 +185,8 @@ int mo_nchw_channel_sum(const float* x, long istride, int C, long n_img, int HW,
                         void* stream);
 /* nn.Dropout (unet.py:135,159) with the counter-based mask; the same call is its own backward */
 int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint32_t thresh, float scale, void* stream);
+/* ReLU backward on a materialised activation y: out = (y > 0) ? dy : 0 (fc layers, unet.py:142-144) */
+int mo_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream);
 
 #ifdef __cplusplus
 }

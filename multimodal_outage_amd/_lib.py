@@ -65,6 +65,7 @@ SIGNATURES = {
                               vp, vp, vp, vp]),
     'mo_nchw_channel_sum': (i32, [vp, i64, i32, i64, i32, vp, vp, vp]),
     'mo_dropout': (i32, [vp, vp, i64, u32, u32, f32, vp]),
+    'mo_relu_bwd': (i32, [vp, vp, vp, i64, vp]),
 }
 
 

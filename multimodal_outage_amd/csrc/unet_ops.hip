@@ -488,3 +488,15 @@ extern "C" int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint3
   hipLaunchKernelGGL(dropout_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), x, y, n, seed, thresh, scale);
   return mo_launch_status();
 }
+
+// ReLU backward on a materialised activation: out = (y > 0) ? dy : 0   (Encoder/Decoder fc, unet.py:142-144)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (y[i] > 0.f) ? dy[i] : 0.f;
+}
+extern "C" int mo_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream) {
+  MO_CHECK_ARG(dy && y && out && n > 0);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), dy, y, out, n);
+  return mo_launch_status();
+}

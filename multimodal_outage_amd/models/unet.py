@@ -1,0 +1,182 @@
+"""Modified UNet -- mirror of reference models/unet.py (constructors, forward, state_dict).
+
+Same class names and state_dict keys/shapes as the reference.  The reference runs
+every block in Python loops over the 67 counties and the batch (unet.py:110,141,165,188,221); here
+``Modified_UNET.forward`` sends all B*67*H tiles through the HIP engine in one batch while keeping the
+reference's per-county train-mode BatchNorm grouping and running-stat update order.
+Module-level hyper-parameters became constructor kwargs with the reference values as defaults; the
+'cuda' literal of unet.py:210 is replaced by the module's device; st_gnn='dcrnn' cannot be built
+because the reference tree itself lacks models/dcrnn.py (unet.py:13).
+"""
+import torch
+import torch.nn as nn
+
+from .graph_wavenet import gwnet, default_supports
+from ..unet_engine import UnetEncodeFn, UnetDecodeFn
+
+# Hyperparameters (unet.py:33-38)
+image_dimension = 128
+n_counties = 67
+feature_vector_size = 256
+time_embed_size = 64
+loc_embed_size = 256
+compression_factor = 4
+
+
+class DoubleConv(nn.Module):
+    """unet.py:40-53 (parameter container; computed inside the batched engine)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True)
+        )
+
+
+class Down(nn.Module):
+    """unet.py:55-65."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
+
+
+class Up(nn.Module):
+    """unet.py:67-84."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+        self.conv = DoubleConv(in_channels, out_channels)
+
+
+class OutConv(nn.Module):
+    """unet.py:86-92."""
+
+    def __init__(self, in_channels, out_channels):
+        super(OutConv, self).__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+
+class Contraction(nn.Module):
+    """unet.py:95-126."""
+
+    def __init__(self, in_channels, horizon):
+        super().__init__()
+        self.horizon = horizon
+        self.inc = (DoubleConv(in_channels, 4))
+        self.down1 = (Down(4, 8))
+        self.down2 = (Down(8, 16))
+        self.down3 = (Down(16, 32))
+        self.down4 = (Down(32, 64))
+        self.feature_maps = [[] for _ in range(4)]
+
+
+class Encoder(nn.Module):
+    """unet.py:128-149."""
+
+    def __init__(self, image_dimension=image_dimension):
+        super(Encoder, self).__init__()
+        self.compression_factor = compression_factor
+        self.downsized_image_dimension = image_dimension / 16
+        self.first_layer_size = int(self.downsized_image_dimension * self.downsized_image_dimension * 64)
+        self.fc1 = nn.Linear(self.first_layer_size, int(self.first_layer_size / self.compression_factor))
+        self.dropout1 = nn.Dropout(p=0.3)
+        self.fc2 = nn.Linear(int(self.first_layer_size / self.compression_factor), feature_vector_size)
+
+
+class Decoder(nn.Module):
+    """unet.py:151-173."""
+
+    def __init__(self, horizon, image_dimension=image_dimension):
+        super(Decoder, self).__init__()
+        self.horizon = horizon
+        self.compression_factor = compression_factor
+        self.downsized_image_dimension = int(image_dimension / 16)
+        self.output_layer_size = int(self.downsized_image_dimension * self.downsized_image_dimension * 64)
+        self.fc1 = nn.Linear(feature_vector_size, int(feature_vector_size * self.compression_factor))
+        self.dropout1 = nn.Dropout(p=0.3)
+        self.fc2 = nn.Linear(int(feature_vector_size * self.compression_factor), self.output_layer_size)
+
+
+class Expansion(nn.Module):
+    """unet.py:175-199."""
+
+    def __init__(self, output_channels):
+        super(Expansion, self).__init__()
+        self.up1 = (Up(64, 32))
+        self.up2 = (Up(32, 16))
+        self.up3 = (Up(16, 8))
+        self.up4 = (Up(8, 4))
+        self.outc = (OutConv(4, output_channels))
+
+
+class Modified_UNET(nn.Module):
+    def __init__(self, st_gnn, horizon, input_channels=3, output_channels=3, n_counties=n_counties,
+                 image_dimension=image_dimension, supports=default_supports, gwnet_kwargs=None):
+        super(Modified_UNET, self).__init__()
+        self.horizon = horizon
+        self.n_counties = n_counties
+        self.image_dimension = image_dimension
+        self.contraction = Contraction(input_channels, self.horizon)
+        if image_dimension == 128:
+            self.encoder = Encoder()
+        else:
+            self.encoder = Encoder(image_dimension)
+        self.st_gnn_in_dim = feature_vector_size + time_embed_size
+        if st_gnn == 'gwnet':
+            kw = dict(in_dim=self.st_gnn_in_dim, out_dim=feature_vector_size, horizon=self.horizon,
+                      num_nodes=n_counties, supports=supports)
+            kw.update(gwnet_kwargs or {})
+            self.st_gnn = gwnet(device='cpu', **kw)
+        elif st_gnn == 'dcrnn':
+            raise NotImplementedError("st_gnn='dcrnn': models/dcrnn.py is absent from the reference tree (unet.py:13)")
+        else:
+            print(f'Please select a valid spatiotemporal graph neural network.')
+        self.decoder = Decoder(self.horizon) if image_dimension == 128 else Decoder(self.horizon, image_dimension)
+        self.expansion = Expansion(output_channels)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _names(self, prefixes):
+        return [k for k, _ in self.named_parameters() if k.split('.')[0] in prefixes]
+
+    def _bufs(self):
+        out = {}
+        for name, m in self.named_modules():
+            if isinstance(m, nn.BatchNorm2d) and not name.startswith('st_gnn'):
+                out[name] = (m.running_mean, m.running_var, m.num_batches_tracked)
+        return out
+
+    def forward(self, input, time_dim):
+        """unet.py:219-231.  input: (B, n_counties, H, Cin, S, S); time_dim: (B, n_counties, H, 64)."""
+        if not input.is_cuda:
+            raise RuntimeError('Modified_UNET runs on the MI355X HIP path only (no CPU fallback)')
+        B, NC, H, Cin, S, _ = input.shape
+        assert NC == self.n_counties and H == self.horizon and S == self.image_dimension
+        n = B * NC * H
+        named = dict(self.named_parameters())
+        state = dict(gsize=H, training=self.training, bufs=self._bufs(),
+                     fc_dropout=self.encoder.dropout1.p)
+        enc_names = self._names(('contraction', 'encoder'))
+        dec_names = self._names(('decoder', 'expansion'))
+        st_e = dict(state, names=enc_names)
+        outs = UnetEncodeFn.apply(st_e, input.reshape(n, Cin, S, S).float(), *[named[k] for k in enc_names])
+        feat, fms = outs[0], outs[1:]
+        feat = feat.view(B, NC, H, feature_vector_size)
+        zs = []
+        for b in range(B):                                       # unet.py:221: one gwnet call per batch element
+            o = torch.cat((feat[b], time_dim[b].to(feat.dtype)), dim=-1)      # (67, H, 320)  unet.py:224
+            zs.append(self.st_gnn(o))                            # (67, H, 256)
+        z = torch.stack(zs).reshape(n, feature_vector_size)
+        st_d = dict(state, names=dec_names, skip_views=st_e['skip_views'],
+                    fc_dropout=self.decoder.dropout1.p)
+        out = UnetDecodeFn.apply(st_d, z, *fms, *[named[k] for k in dec_names])
+        return out.view(B, NC, H, out.shape[1], S, S)
+
+
+UNet = Modified_UNET   # the name used by the north star for models.unet

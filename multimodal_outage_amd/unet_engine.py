@@ -1,0 +1,328 @@
+"""Host-side orchestration of the UNet encoder/decoder (unet.py:95-199) on the HIP C-ABI.
+
+All B*n_counties*H tiles are processed in one batch of NCHW images (image index = (b*n_counties +
+county)*H + h); BatchNorm runs per group of H images, i.e. exactly the statistics of the reference's
+per-county calls, and running stats receive the same sequential county-then-batch updates
+(SURVEY.md F7).  Two autograd Functions: ``UnetEncodeFn`` (Contraction + Encoder) and
+``UnetDecodeFn`` (Decoder + Expansion); the skip feature maps travel between them as raw conv
+outputs whose "gradient" is defined as the gradient w.r.t. their activated view.
+"""
+import torch
+
+from . import _lib as L
+
+ENC_CH = ((4, 8), (8, 16), (16, 32), (32, 64))      # down1..4 (unet.py:100-103)
+DEC_CH = ((64, 32), (32, 16), (16, 8), (8, 4))      # up1..4   (unet.py:178-181)
+
+
+class View:
+    """An activated view: raw NCHW tensor + per-(group,channel) folded BatchNorm affine + ReLU."""
+
+    def __init__(self, t, C, H, W, sc=None, sh=None):
+        self.t, self.C, self.H, self.W, self.sc, self.sh = t, C, H, W, sc, sh
+
+    @property
+    def istride(self):
+        return self.C * self.H * self.W
+
+    def args(self):
+        return (L.ptr(self.t), self.C, self.istride, L.ptr(self.sc), L.ptr(self.sh), 1 if self.sc is not None else 0)
+
+
+_NOVIEW = (None, 0, 0, None, None, 0)
+
+
+def _empty(*shape, dev):
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev):
+    v0 = views[0]
+    H, W = v0.H, v0.W
+    st = L.stream()
+    y = _empty(n, Co, H, W, dev=dev)
+    a1 = views[1].args() if len(views) > 1 else _NOVIEW
+    L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, st)
+    G = n // gs
+    aff = _empty(4, G, Co, dev=dev)            # scale, shift, mean, rstd
+    stats = None
+    if training:
+        stats = _empty(n, Co, 2, dev=dev)
+        L.call('mo_nchw_stats', L.ptr(y), Co * H * W, Co, n, H * W, L.ptr(stats), st)
+    rm, rv, nbt = bufs[bnkey]
+    L.call('mo_group_bn_finalize', L.ptr(stats), n, Co, gs, H * W, L.ptr(p[bnkey + '.weight']),
+           L.ptr(p[bnkey + '.bias']), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, 1 if training else 0,
+           L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(aff[2]), L.ptr(aff[3]), st)
+    if training:
+        nbt += G
+    return y, aff
+
+
+def double_conv_fwd(p, pre, views, Co, n, gs, training, bufs, dev):
+    """unet.py:40-53.  Returns (saved, output view)."""
+    H, W = views[0].H, views[0].W
+    y1, aff1 = _conv_bn(p, pre + '.double_conv.0.weight', pre + '.double_conv.1', views, Co, n, gs, training, bufs, dev)
+    v1 = View(y1, Co, H, W, aff1[0], aff1[1])
+    y2, aff2 = _conv_bn(p, pre + '.double_conv.3.weight', pre + '.double_conv.4', [v1], Co, n, gs, training, bufs, dev)
+    v2 = View(y2, Co, H, W, aff2[0], aff2[1])
+    return dict(pre=pre, views=views, y1=y1, aff1=aff1, v1=v1, y2=y2, aff2=aff2, Co=Co, H=H, W=W), v2
+
+
+def _flip(W, dev):
+    Co, Ci = W.shape[0], W.shape[1]
+    Wf = _empty(Ci, Co, 3, 3, dev=dev)
+    L.call('mo_conv3x3_flip_weights', L.ptr(W), Co, Ci, L.ptr(Wf), L.stream())
+    return Wf
+
+
+def _dastride(t):
+    """Image stride of a gradient tensor that is contiguous within each image (channel slices allowed)."""
+    if t is None:
+        return None, 0
+    n, C, H, W = t.shape
+    assert t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W, 'gradient must be image-contiguous'
+    return t, t.stride(0)
+
+
+def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=True):
+    """Backward of DoubleConv.  da: gradient w.r.t. the activated output view (may be a channel slice of
+    a wider buffer), dp: gradient w.r.t. its 2x2 max-pooled version.  Returns the gradient w.r.t. the
+    (activated) channel-concatenated input, shape (n, C0+C1, H, W), or None."""
+    lib = L.load()
+    st = L.stream()
+    pre, Co, H, W = sv['pre'], sv['Co'], sv['H'], sv['W']
+    HW = H * W
+
+    def act_bwd(y, aff, bnkey, da_t, dp_t):
+        dy = _empty(n, Co, H, W, dev=dev)
+        dg = _empty(Co, dev=dev)
+        db = _empty(Co, dev=dev)
+        ws = torch.empty(lib.mo_unet_act_bwd_ws_floats(n, Co), device=dev, dtype=torch.float32)
+        da_t, das = _dastride(da_t)
+        L.call('mo_unet_act_bwd', L.ptr(y), Co * HW, Co, n, H, W, gs, L.ptr(p[bnkey + '.weight']), L.ptr(aff[2]),
+               L.ptr(aff[3]), L.ptr(aff[0]), L.ptr(aff[1]), da_t.data_ptr() if da_t is not None else None, das,
+               L.ptr(dp_t), (Co * HW) // 4, L.ptr(dy), Co * HW, L.ptr(dg), L.ptr(db), L.ptr(ws), st)
+        grads[bnkey + '.weight'], grads[bnkey + '.bias'] = dg, db
+        return dy
+
+    def wgrad(dy, views, wkey):
+        Ci = sum(v.C for v in views)
+        dW = _empty(Co, Ci, 3, 3, dev=dev)
+        ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * HW), device=dev, dtype=torch.float32)
+        a1 = views[1].args() if len(views) > 1 else _NOVIEW
+        L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * HW, Co, *views[0].args(), *a1, gs, n, H, W, L.ptr(dW),
+               L.ptr(ws), st)
+        grads[wkey] = dW
+
+    def dgrad(dy, Wt):
+        Ci = Wt.shape[1]
+        Wf = _flip(Wt, dev)
+        dx = _empty(n, Ci, H, W, dev=dev)
+        L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wf), Ci, n, H, W,
+               L.ptr(dx), Ci * HW, st)
+        return dx
+
+    dy2 = act_bwd(sv['y2'], sv['aff2'], pre + '.double_conv.4', da, dp)
+    wgrad(dy2, [sv['v1']], pre + '.double_conv.3.weight')
+    da1 = dgrad(dy2, p[pre + '.double_conv.3.weight'])
+    dy1 = act_bwd(sv['y1'], sv['aff1'], pre + '.double_conv.1', da1, None)
+    wgrad(dy1, sv['views'], pre + '.double_conv.0.weight')
+    if not need_input_grad:
+        return None
+    return dgrad(dy1, p[pre + '.double_conv.0.weight'])
+
+
+def _fc_fwd(x, W, b, relu):
+    P, Ci = x.shape
+    Co = W.shape[0]
+    out = _empty(P, Co, dev=x.device)
+    L.call('mo_conv1x1_fwd', L.ptr(x), Ci, 0, 0, 0, 0, L.ptr(W), L.ptr(b), Co, L.ptr(out), P, 1 if relu else 0, 0,
+           L.stream())
+    return out
+
+
+def _dropout(x, seed, thresh, scale):
+    if not thresh:
+        return x
+    y = torch.empty_like(x)
+    L.call('mo_dropout', L.ptr(x), L.ptr(y), x.numel(), seed, thresh, scale, L.stream())
+    return y
+
+
+def fc_block_fwd(p, pre, x, drop):
+    """unet.py:138-149 / :162-173: relu(fc1) -> dropout -> relu(fc2) on rows of x."""
+    h1 = _fc_fwd(x, p[pre + '.fc1.weight'], p[pre + '.fc1.bias'], True)
+    d1 = _dropout(h1, *drop)
+    h2 = _fc_fwd(d1, p[pre + '.fc2.weight'], p[pre + '.fc2.bias'], True)
+    return dict(pre=pre, x=x, h1=h1, d1=d1, h2=h2, drop=drop), h2
+
+
+def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True):
+    lib = L.load()
+    st = L.stream()
+    pre, x, h1, d1, h2 = sv['pre'], sv['x'], sv['h1'], sv['d1'], sv['h2']
+    dev = x.device
+    P = x.shape[0]
+
+    def lin_bwd(dout, inp, wkey, bkey, need_in):
+        W = p[wkey]
+        Co, Ci = W.shape
+        dW = torch.empty_like(W)
+        db = _empty(Co, dev=dev)
+        ws = torch.empty(lib.mo_wgrad_ws_floats(Co, Ci, P), device=dev, dtype=torch.float32)
+        L.call('mo_conv1x1_bwd_weight', L.ptr(dout), Co, P, L.ptr(inp), Ci, 0, 0, 0, 0, L.ptr(dW), L.ptr(db), L.ptr(ws), st)
+        grads[wkey], grads[bkey] = dW, db
+        if not need_in:
+            return None
+        din = _empty(P, Ci, dev=dev)
+        L.call('mo_conv1x1_bwd_data', L.ptr(dout), Co, P, L.ptr(W), Ci, L.ptr(din), 0, 0, 0, None, 0, st)
+        return din
+
+    dh2 = dh2.contiguous()
+    da2 = torch.empty_like(dh2)
+    L.call('mo_relu_bwd', L.ptr(dh2), L.ptr(h2), L.ptr(da2), da2.numel(), st)
+    dd1 = lin_bwd(da2, d1, pre + '.fc2.weight', pre + '.fc2.bias', True)
+    dh1 = _dropout(dd1, *sv['drop'])
+    da1 = torch.empty_like(dh1)
+    L.call('mo_relu_bwd', L.ptr(dh1), L.ptr(h1), L.ptr(da1), da1.numel(), st)
+    return lin_bwd(da1, x, pre + '.fc1.weight', pre + '.fc1.bias', need_input_grad)
+
+
+def _drop_params(p_drop, training):
+    if not training or p_drop <= 0:
+        return (0, 0, 1.0)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return (seed, int(min(p_drop, 0.999999) * 4294967296.0), 1.0 / (1.0 - p_drop))
+
+
+class UnetEncodeFn(torch.autograd.Function):
+    """Contraction + Encoder (unet.py:106-126, 138-149) over all tiles.
+    x: (n_img, Cin, S, S) -> feat (n_img, 256), fm1..fm4 (raw second-conv outputs of inc, down1..3)."""
+
+    @staticmethod
+    def forward(ctx, state, x, *params):
+        p = dict(zip(state['names'], params))
+        dev = x.device
+        n, Cin, S, _ = x.shape
+        gs, training, bufs = state['gsize'], state['training'], state['bufs']
+        x = x.contiguous()
+        st = L.stream()
+        saved = []
+        sv, v = double_conv_fwd(p, 'contraction.inc', [View(x, Cin, S, S)], 4, n, gs, training, bufs, dev)
+        saved.append(sv)
+        views = [v]
+        for k, (ci, co) in enumerate(ENC_CH, 1):
+            H = v.H
+            pooled = _empty(n, ci, H // 2, H // 2, dev=dev)
+            L.call('mo_unet_act', L.ptr(v.t), v.istride, ci, n, H, H, L.ptr(v.sc), L.ptr(v.sh), gs, 1, L.ptr(pooled),
+                   ci * (H // 2) * (H // 2), st)
+            sv, v = double_conv_fwd(p, f'contraction.down{k}.maxpool_conv.1', [View(pooled, ci, H // 2, H // 2)], co, n,
+                                    gs, training, bufs, dev)
+            saved.append(sv)
+            views.append(v)
+        v5 = views[-1]
+        x5a = _empty(n, v5.C, v5.H, v5.W, dev=dev)
+        L.call('mo_unet_act', L.ptr(v5.t), v5.istride, v5.C, n, v5.H, v5.W, L.ptr(v5.sc), L.ptr(v5.sh), gs, 0, L.ptr(x5a),
+               v5.istride, st)
+        fc_sv, feat = fc_block_fwd(p, 'encoder', x5a.view(n, -1), _drop_params(state['fc_dropout'], training))
+        state['skip_views'] = views[:4]
+        ctx.state, ctx.p, ctx.saved, ctx.fc_sv, ctx.n = state, p, saved, fc_sv, n
+        ctx.x_needs_grad = x.requires_grad
+        return (feat,) + tuple(v.t for v in views[:4])
+
+    @staticmethod
+    def backward(ctx, dfeat, dfm1, dfm2, dfm3, dfm4):
+        state, p, saved, n = ctx.state, ctx.p, ctx.saved, ctx.n
+        gs = state['gsize']
+        dev = dfeat.device
+        grads = {}
+        dx5a = fc_block_bwd(p, ctx.fc_sv, dfeat, grads)
+        v5 = saved[4]
+        dp = double_conv_bwd(p, saved[4], n, gs, grads, dev, da=dx5a.view(n, v5['Co'], v5['H'], v5['W']), dp=None)
+        dfm = [dfm1, dfm2, dfm3, dfm4]
+        for k in (3, 2, 1, 0):
+            need = (k > 0) or ctx.x_needs_grad
+            dp = double_conv_bwd(p, saved[k], n, gs, grads, dev, da=dfm[k], dp=dp, need_input_grad=need)
+        return (None, dp) + tuple(grads.get(k) for k in state['names'])
+
+
+class UnetDecodeFn(torch.autograd.Function):
+    """Decoder + Expansion (unet.py:162-173, 184-199).  z: (n_img, 256) and the four skip maps."""
+
+    @staticmethod
+    def forward(ctx, state, z, fm1, fm2, fm3, fm4, *params):
+        p = dict(zip(state['names'], params))
+        dev = z.device
+        n = z.shape[0]
+        gs, training, bufs = state['gsize'], state['training'], state['bufs']
+        st = L.stream()
+        fc_sv, h2 = fc_block_fwd(p, 'decoder', z.contiguous(), _drop_params(state['fc_dropout'], training))
+        S0 = state['skip_views'][3].H // 2
+        v = View(h2.view(n, 64, S0, S0), 64, S0, S0)
+        skips = state['skip_views']
+        ups = []
+        for k, (ci, co) in enumerate(DEC_CH, 1):
+            H = v.H
+            u = _empty(n, ci // 2, 2 * H, 2 * H, dev=dev)
+            L.call('mo_convt2x2_fwd', L.ptr(v.t), v.istride, ci, L.ptr(v.sc), L.ptr(v.sh), 1 if v.sc is not None else 0,
+                   gs, L.ptr(p[f'expansion.up{k}.up.weight']), L.ptr(p[f'expansion.up{k}.up.bias']), ci // 2, n, H, H,
+                   L.ptr(u), (ci // 2) * 4 * H * H, st)
+            sk = skips[4 - k]
+            if sk.H != 2 * H:
+                raise NotImplementedError('Up padding (unet.py:76-81) is only needed for odd sizes')
+            sv, vn = double_conv_fwd(p, f'expansion.up{k}.conv', [sk, View(u, ci // 2, 2 * H, 2 * H)], co, n, gs,
+                                     training, bufs, dev)
+            ups.append(dict(vin=v, dc=sv, ci=ci, H=H))
+            v = vn
+        Wo, bo = p['expansion.outc.conv.weight'], p['expansion.outc.conv.bias']
+        Cout = Wo.shape[0]
+        out = _empty(n, Cout, v.H, v.W, dev=dev)
+        L.call('mo_nchw_conv1x1_fwd', L.ptr(v.t), v.istride, v.C, L.ptr(v.sc), L.ptr(v.sh), 1, gs, L.ptr(Wo), L.ptr(bo),
+               Cout, n, v.H * v.W, L.ptr(out), Cout * v.H * v.W, st)
+        ctx.state, ctx.p, ctx.fc_sv, ctx.ups, ctx.vlast, ctx.n = state, p, fc_sv, ups, v, n
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        state, p, n, v = ctx.state, ctx.p, ctx.n, ctx.vlast
+        lib = L.load()
+        gs = state['gsize']
+        dev = dout.device
+        st = L.stream()
+        grads = {}
+        dout = dout.contiguous()
+        Wo = p['expansion.outc.conv.weight']
+        Cout, C4 = Wo.shape[0], Wo.shape[1]
+        HW = v.H * v.W
+        dWo = torch.empty_like(Wo)
+        ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), device=dev, dtype=torch.float32)
+        L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Cout * HW, Cout, L.ptr(v.t), v.istride, C4, L.ptr(v.sc),
+               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(ws), st)
+        dbo = _empty(Cout, dev=dev)
+        ws2 = _empty(n * Cout * 2, dev=dev)
+        L.call('mo_nchw_channel_sum', L.ptr(dout), Cout * HW, Cout, n, HW, L.ptr(dbo), L.ptr(ws2), st)
+        grads['expansion.outc.conv.weight'], grads['expansion.outc.conv.bias'] = dWo, dbo
+        da = _empty(n, C4, v.H, v.W, dev=dev)
+        L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW, st)
+        dfm = [None] * 4
+        for k in (4, 3, 2, 1):
+            up = ctx.ups[k - 1]
+            ci, H, vin = up['ci'], up['H'], up['vin']
+            dcat = double_conv_bwd(p, up['dc'], n, gs, grads, dev, da=da, dp=None)     # (n, ci, 2H, 2H)
+            C0 = ci // 2
+            dfm[4 - k] = dcat[:, :C0]
+            du = dcat[:, C0:]
+            du_stride = dcat.stride(0)
+            Wt = p[f'expansion.up{k}.up.weight']
+            dWt = torch.empty_like(Wt)
+            wsu = torch.empty(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), device=dev, dtype=torch.float32)
+            L.call('mo_convt2x2_bwd_weight', du.data_ptr(), du_stride, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
+                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(wsu), st)
+            dbt = _empty(C0, dev=dev)
+            wsb = _empty(n * C0 * 2, dev=dev)
+            L.call('mo_nchw_channel_sum', du.data_ptr(), du_stride, C0, n, 4 * H * H, L.ptr(dbt), L.ptr(wsb), st)
+            grads[f'expansion.up{k}.up.weight'], grads[f'expansion.up{k}.up.bias'] = dWt, dbt
+            da = _empty(n, ci, H, H, dev=dev)
+            L.call('mo_convt2x2_bwd_data', du.data_ptr(), du_stride, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
+        dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads)
+        return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + tuple(grads.get(k) for k in state['names'])

@@ -1,0 +1,65 @@
+"""world_size-2 gloo test of the data-parallel plumbing (runs on CPU): rank-0 broadcast of the flat
+parameter buffer and buffers, one-bucket gradient all-reduce with 1/world averaging, identical
+handling of never-touched (zero) gradients on all ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from multimodal_outage_amd.trainer import FlatTrainer
+        torch.manual_seed(100 + rank)                 # ranks start with DIFFERENT weights
+        m = nn.Sequential(nn.Conv2d(3, 5, 1), nn.BatchNorm2d(5), nn.Linear(7, 2))
+        m[1].running_mean.fill_(float(rank))
+        tr = FlatTrainer(m)
+        # after construction every rank holds rank 0's parameters and buffers
+        ref = [torch.zeros_like(tr.flat_p) for _ in range(world)]
+        dist.all_gather(ref, tr.flat_p)
+        same = all(torch.equal(ref[0], r) for r in ref)
+        buf_ok = float(m[1].running_mean[0]) == 0.0
+        # parameters are views of the flat buffer; grads are views of the flat grad buffer
+        views_ok = all(p.data_ptr() >= tr.flat_p.data_ptr() for p in m.parameters())
+        # rank-dependent gradients; one parameter (the Linear bias) is never touched -> stays zero
+        for k, g in tr.grad_views.items():
+            if k != '2.bias':
+                g.fill_(float(rank + 1))
+        tr.allreduce()
+        summed = {k: float(g.flatten()[0]) for k, g in tr.grad_views.items()}
+        q.put((rank, same, buf_ok, views_ok, summed, tr.world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_trainer_gloo_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, buf_ok, views_ok, summed, w in res:
+        assert same and buf_ok and views_ok and w == 2
+        for k, v in summed.items():
+            assert v == (0.0 if k == '2.bias' else 3.0), (k, v)     # 1 + 2 summed; Adam divides by world

@@ -151,8 +151,31 @@ def modified_unet_case(name, B, H, seed):
              seed=np.int64(seed))
     d.update(grad_summary(m, max_full=1100))
     d.update(buffers(m))
+    # the same step in float64 (same class bodies): the yardstick for fp32 rounding noise of the
+    # gradients, which are sums over millions of pixels with heavy cancellation
+    m64 = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=1, output_channels=1)
+    P.load_into(m64, P.seeded_values(schema, seed))
+    m64.st_gnn.dropout = 0.0
+    for g in m64.st_gnn.gconv:
+        g.dropout = 0.0
+    m64.encoder.dropout1.p = 0.0
+    m64.decoder.dropout1.p = 0.0
+    m64 = m64.double().train()
+    m64.st_gnn.supports = [s_.double() for s_ in m64.st_gnn.supports]
+    y64 = m64(x.double(), tdim.double())
+    loss64 = F.mse_loss(y64, tgt.double())
+    loss64.backward()
+    d['loss64'] = np.float64(loss64.item())
+    for k, prm in m64.named_parameters():
+        if prm.grad is None:
+            continue
+        g = prm.grad.detach().numpy()
+        if g.size <= 1100:
+            d['grad64/' + k] = g
+        else:
+            d['gsample64/' + k] = g.reshape(-1)[::max(1, g.size // 2048)][:2048].copy()
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
-    print(name, 'loss', loss.item())
+    print(name, 'loss', loss.item(), 'loss64', loss64.item())
 
 
 def csr_case():
