@@ -29,6 +29,7 @@ N_NODES, C_IN, T_IN, OUT_DIM, KSIZE = 3000, 32, 12, 12, 2
 # compulsory fp32 tensor traffic per window, forward; fwd+bwd counted as 3x
 ALG_BYTES_FWD_PER_WINDOW = 768.7e6
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -91,6 +92,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='windows per GPU per step (weak scaling)')
+    ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16',
+                    help='operand type of the dense adaptive-adjacency products (fp32 accumulate either way)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     args = ap.parse_args()
@@ -120,6 +123,7 @@ def main():
     torch.manual_seed(42)         # lit.py:14
     model = gwnet('cpu', num_nodes=N_NODES, dropout=0.3, supports=supports, in_dim=C_IN, out_dim=OUT_DIM,
                   kernel_size=KSIZE, blocks=4, layers=2).to(dev).train()
+    model.dense_dtype = args.dtype
     trainer = FlatTrainer(model, lr=1e-3)
     model._mo_grad_out = trainer.grad_out()
     B = args.batch
@@ -166,10 +170,13 @@ def main():
     gemm_flops = sum(f for (_, f, _, _) in prof)
     n_launch = max(len(prof), 1)
     ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "mo_gemm_kernel<128,128,16> dense adaptive-adjacency product "
-                                           "(mo_adj_gemm fwd/bwd-data + mo_adj_grad)",
-                "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+    kname = ("gemm_bf16_kernel<128x128x32, mfma_f32_32x32x16_bf16>" if args.dtype == 'bf16'
+             else "mo_gemm_kernel<128,128,16, mfma_f32_32x32x2_f32>")
+    roofline = {"bound": "mfma", "kernel": kname + " dense adaptive-adjacency node-axis product "
+                                                   "(forward, data-gradient and dA launches)",
+                "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4),
                 "launches": len(prof), "avg_launch_ms": round(gemm_ms / n_launch, 4),
                 "avg_launch_gflop": round(gemm_flops / n_launch / 1e9, 3),
                 "traffic": None}
@@ -187,7 +194,7 @@ def main():
     line = {"metric": "train windows/sec (gwnet N=3k,T=12)", "value": round(windows_per_s, 3),
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "gwnet fwd+MSE+bwd+Adam on (B,32,3000,12) graph windows, kernel_size=2, "
                                    "blocks=4, layers=2, 2 static k-NN supports (CSR, nnz 17996 each) + dense "
                                    "adaptive adjacency, dropout 0.3",

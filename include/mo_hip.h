@@ -83,6 +83,14 @@ int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, long J, int 
 /* dA[v][w] (+)= sum_j X[v][j] * dY[w][j]   (gradient of the adaptive adjacency) */
 int mo_adj_grad(const float* X, const float* dY, int N, long J, float* dA, int beta, void* stream);
 
+/* bf16-operand / fp32-accumulate variants of the dense products (the throughput mode of BASELINE
+ * config 2): D[M][N] (+)= A[M][K] * B, A bf16 k-contiguous, B bf16 either [K][N] (b_krows=1: the nbtc
+ * activation matrix as stored; fetched with ds_read_b64_tr_b16) or [N][K] (b_krows=0).  lda, ldb, K
+ * (and N when b_krows) must be multiples of 8.  mo_f32_to_bf16: round-to-nearest-even, n % 8 == 0. */
+int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
+                 int N, int K, int beta, void* stream);
+int mo_f32_to_bf16(const float* x, void* y, long n, void* stream);
+
 /* ---- gcn mlp + dropout + residual + BatchNorm statistics (graph_wavenet.py:95-97,247,250) -------
  * h[p][:] = drop(W @ cat[srcs[0..ns)][p] + b) + (res[(g,t+Tin-Tout)]*rscale+rshift); per-block BN
  * partial sums go to `partial` (mo_mlp_partial_floats(P) floats). ns = 2S+1 sources of [P][32].

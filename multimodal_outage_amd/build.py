@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmo_hip.so')
-SOURCES = ['gwnet_ops.hip', 'unet_ops.hip', 'comm.cpp']
+SOURCES = ['gwnet_ops.hip', 'unet_ops.hip', 'gemm_bf16.hip']
 
 
 def _stale():

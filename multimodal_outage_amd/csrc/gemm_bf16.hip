@@ -1,0 +1,183 @@
+// bf16-operand / fp32-accumulate GEMM for the dense adaptive-adjacency node-axis products on gfx950.
+//
+//   D[M][N] (+)= sum_k A[m][k] * B(k, n)
+//   A: bf16 [M][K], k contiguous (adp^T for the forward product, adp for its data gradient, X for dA)
+//   B: bf16, either KROWS [K][N] (n contiguous: the nbtc activation matrix X[v][j] as it lies in HBM,
+//      fragments fetched with the gfx950 transposing LDS read ds_read_b64_tr_b16) or XROWS [N][K]
+//   D: fp32 row-major.
+// 128x128x32 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_32x32x16_bf16, register-prefetched double
+// buffered LDS.  LDS rows are padded so that the ds_read_b128 fragment reads (80-byte rows) and the
+// transposing reads (320-byte rows) are bank-conflict free (MI355X_MICROARCH.md, LDS section).
+#include "mo_common.h"
+#include "../../include/mo_hip.h"
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
+
+#define GB_BM 128
+#define GB_BN 128
+#define GB_BK 32
+#define GB_LDA 40    // bf16 elements per LDS row of an [x][k] tile (64 B data + 16 B pad)
+#define GB_LDB 160   // bf16 elements per LDS row of a  [k][n] tile (256 B data + 64 B pad)
+
+__device__ __forceinline__ uint4 gb_load16(const short* base, long row, int ld, int col, int rows, int cols) {
+  // 8 consecutive bf16 at (row, col..col+7); zero outside [rows) x [cols) (cols % 8 == 0 is required)
+  if (row < rows && col < cols) return *reinterpret_cast<const uint4*>(base + row * (long)ld + col);
+  return make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <bool B_KROWS>
+__global__ void __launch_bounds__(256)
+gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ D,
+                 int ldd, int M, int N, int K, int beta) {
+  __shared__ __attribute__((aligned(16))) short As[2][GB_BM * GB_LDA];
+  __shared__ __attribute__((aligned(16))) short Bs[2][B_KROWS ? GB_BK * GB_LDB : GB_BN * GB_LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int m0 = blockIdx.x * GB_BM, n0 = blockIdx.y * GB_BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // tile loads: 512 16-byte chunks per operand, 2 per thread
+  uint4 ra[2], rb[2];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + i * 256;
+      {  // A: [128 rows][4 chunks of 8 k]
+        const int x = f >> 2, c = f & 3;
+        ra[i] = gb_load16(A, m0 + x, lda, k0 + 8 * c, M, K);
+      }
+      if (B_KROWS) {  // B: [32 k rows][16 chunks of 8 n]
+        const int k = f >> 4, c = f & 15;
+        rb[i] = gb_load16(B, k0 + k, ldb, n0 + 8 * c, K, N);
+      } else {
+        const int x = f >> 2, c = f & 3;
+        rb[i] = gb_load16(B, n0 + x, ldb, k0 + 8 * c, N, K);
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + i * 256;
+      {
+        const int x = f >> 2, c = f & 3;
+        *reinterpret_cast<uint4*>(&As[buf][x * GB_LDA + 8 * c]) = ra[i];
+      }
+      if (B_KROWS) {
+        const int k = f >> 4, c = f & 15;
+        *reinterpret_cast<uint4*>(&Bs[buf][k * GB_LDB + 8 * c]) = rb[i];
+      } else {
+        const int x = f >> 2, c = f & 3;
+        *reinterpret_cast<uint4*>(&Bs[buf][x * GB_LDA + 8 * c]) = rb[i];
+      }
+    }
+  };
+
+  const int nk = (K + GB_BK - 1) / GB_BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int fr = lane & 31, fh = lane >> 5;
+  // transposing-read geometry (16-lane groups): group g -> k half (g>>1), column half (g&1)
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles((kt + 1) * GB_BK);
+    const short* Ac = As[cur];
+    const short* Bc = Bs[cur];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v8s a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const v8s*>(&Ac[(wm0 + i * 32 + fr) * GB_LDA + 16 * s + 8 * fh]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (B_KROWS) {
+          const int kr = 16 * s + 8 * (tg >> 1) + tq;
+          const int nc = wn0 + j * 32 + 16 * (tg & 1) + 4 * tp;
+          v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)&Bc[kr * GB_LDB + nc]);
+          v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)&Bc[(kr + 4) * GB_LDB + nc]);
+          b[j] = (v8s){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+          b[j] = *reinterpret_cast<const v8s*>(&Bc[(wn0 + j * 32 + fr) * GB_LDA + 16 * s + 8 * fh]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[i]),
+                                                               __builtin_bit_cast(v8bf, b[j]), acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn0 + j * 32 + fr;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m >= M) continue;
+        float* o = D + (long)m * ldd + n;
+        float v = acc[i][j][r];
+        if (beta) v += *o;
+        *o = v;
+      }
+    }
+}
+
+extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
+                            int N, int K, int beta, void* stream) {
+  MO_CHECK_ARG(A && B && D && M > 0 && N > 0 && K > 0);
+  // 16-byte chunk loads: leading dimensions and the contiguous extents must be multiples of 8 elements
+  MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (K % 8) == 0 && (!b_krows || (N % 8) == 0));
+  MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
+  dim3 grid(mo_cdiv(M, GB_BM), mo_cdiv(N, GB_BN));
+  if (b_krows)
+    hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)A, lda,
+                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+  else
+    hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)A, lda,
+                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+  return mo_launch_status();
+}
+
+// fp32 -> bf16 (round to nearest even; plain cast so that NaNs stay NaNs), 8 elements per thread
+__global__ void f32_to_bf16_kernel(const float4* __restrict__ x, uint4* __restrict__ y, long n8) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = x[2 * i], b = x[2 * i + 1];
+  const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned short h[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { __bf16 t = (__bf16)f[q]; h[q] = __builtin_bit_cast(unsigned short, t); }
+  uint4 o;
+  o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
+  o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+  y[i] = o;
+}
+extern "C" int mo_f32_to_bf16(const float* x, void* y, long n, void* stream) {
+  MO_CHECK_ARG(x && y && n > 0 && (n % 8) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0);
+  long n8 = n / 8;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(mo_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (uint4*)y, n8);
+  return mo_launch_status();
+}

@@ -53,6 +53,7 @@ class GwnetConfig:
         self.gcn, self.adaptive, self.dropout = gcn, adaptive, dropout
         self.names = names            # parameter order of the autograd Function
         self.grad_out = None          # optional {name: preallocated grad tensor} (flat-buffer trainer)
+        self.dense_bf16 = False       # bf16 operands (fp32 accumulate) for the dense adaptive products
 
 
 # Optional live kernel timing (bench.py roofline leg): when PROFILE is a list, every dense
@@ -72,6 +73,23 @@ def _dense(name, N, J, *args):
     L.call(name, *args)
     e1.record()
     PROFILE.append((name, flops, e0, e1))
+
+
+def _bf16(x):
+    """fp32 -> bf16 copy (round to nearest even) for the bf16-operand dense products."""
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    L.call('mo_f32_to_bf16', L.ptr(x), L.ptr(y), x.numel(), L.stream())
+    return y
+
+
+def _adj_prod(A_bf, X_bf, Y, N, J, beta):
+    """Y[N][J] (+)= A_bf[N][N(k)] @ X_bf[N(k)][J]   (bf16 operands, fp32 accumulate)."""
+    _dense('mo_gemm_bf16', N, J, L.ptr(A_bf), N, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta, L.stream())
+
+
+def _adj_grad_bf(X_bf, dY_bf, dA, N, J, beta):
+    """dA[N][N] (+)= X_bf[N][J] @ dY_bf[N][J]^T."""
+    _dense('mo_gemm_bf16', N, J, L.ptr(X_bf), J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta, L.stream())
 
 
 def _spmm(csr, n, X, Y, J, beta):
@@ -108,6 +126,10 @@ class GwnetFunction(torch.autograd.Function):
             adpT = _e(N, N, dev)
             L.call('mo_adp_fwd', L.ptr(p['nodevec1']), L.ptr(p['nodevec2']), N, p['nodevec1'].shape[1],
                    L.ptr(adp), L.ptr(adpT), st)
+        use_bf = bool(cfg.dense_bf16 and adp is not None and N % 8 == 0)
+        adp_bf = adpT_bf = None
+        if use_bf:
+            adp_bf, adpT_bf = _bf16(adp), _bf16(adpT)
         skip = _e(G * Tf, cfg.Cs, dev)
         drop_p = cfg.dropout if training else 0.0
         thresh = int(min(max(drop_p, 0.0), 0.999999) * 4294967296.0) if drop_p > 0 else 0
@@ -133,6 +155,7 @@ class GwnetFunction(torch.autograd.Function):
                    L.ptr(p[f'skip_convs.{i}.weight']), L.ptr(p[f'skip_convs.{i}.bias']), cfg.Cs,
                    L.ptr(skip), G * Tf, 0, 1 if i > 0 else 0, st)
             srcs = [g]
+            bf_saved = None
             if cfg.gcn:
                 for s in statics:
                     x1 = _e(P, 32, dev)
@@ -143,8 +166,15 @@ class GwnetFunction(torch.autograd.Function):
                 if cfg.adaptive:
                     x1 = _e(P, 32, dev)
                     x2 = _e(P, 32, dev)
-                    _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, st)
-                    _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, st)
+                    if use_bf:
+                        g_bf = _bf16(g)
+                        _adj_prod(adpT_bf, g_bf, x1, N, J, 0)
+                        x1_bf = _bf16(x1)
+                        _adj_prod(adpT_bf, x1_bf, x2, N, J, 0)
+                        bf_saved = (g_bf, x1_bf)
+                    else:
+                        _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, st)
+                        _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, st)
                     srcs += [x1, x2]
                 W, bb = p[f'gconv.{i}.mlp.mlp.weight'], p[f'gconv.{i}.mlp.mlp.bias']
                 lt, ls, seed = thresh, dscale, (base_seed + 7919 * i) & 0xFFFFFFFF
@@ -161,7 +191,7 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_bn_finalize', L.ptr(partial), nblk, P, L.ptr(p[f'bn.{i}.weight']),
                    L.ptr(p[f'bn.{i}.bias']), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, 1 if training else 0,
                    L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), st)
-            layers.append(dict(h_in=h, scale=scale, shift=shift, Wp=Wp, g=g, srcs=srcs, h=hn,
+            layers.append(dict(h_in=h, scale=scale, shift=shift, Wp=Wp, g=g, srcs=srcs, h=hn, bf=bf_saved,
                                stats=stats, Tin=Tin, Tout=Tout, seed=seed, thresh=lt, dscale=ls))
             h, scale, shift, Tin = hn, stats[0], stats[1], Tout
 
@@ -178,6 +208,7 @@ class GwnetFunction(torch.autograd.Function):
         ctx.cfg, ctx.statics, ctx.training = cfg, statics, training
         ctx.dims = (B, N, T, Tp, Tf, G)
         ctx.layers, ctx.x_int, ctx.adp, ctx.adpT, ctx.skip, ctx.r1 = layers, x_int, adp, adpT, skip, r1
+        ctx.adp_bf = adp_bf
         ctx.params = p
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -277,12 +308,22 @@ class GwnetFunction(torch.autograd.Function):
                     if cfg.adaptive:
                         x1 = srcs[k]
                         dx1, dx2 = dsrcs[k], dsrcs[k + 1]
-                        _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, st)
-                        _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
-                               1 if dAdp_started else 0, st)
-                        dAdp_started = True
-                        _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx1), L.ptr(dg), J, 1, st)
-                        _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, st)
+                        if ly['bf'] is not None:
+                            g_bf, x1_bf = ly['bf']
+                            dx2_bf = _bf16(dx2)
+                            _adj_prod(ctx.adp_bf, dx2_bf, dx1, N, J, 1)
+                            _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
+                            dAdp_started = True
+                            dx1_bf = _bf16(dx1)
+                            _adj_prod(ctx.adp_bf, dx1_bf, dg, N, J, 1)
+                            _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
+                        else:
+                            _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, st)
+                            _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
+                                   1 if dAdp_started else 0, st)
+                            dAdp_started = True
+                            _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx1), L.ptr(dg), J, 1, st)
+                            _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, st)
                 beta = 1
             else:
                 dg = torch.zeros((P, 32), device=dev, dtype=torch.float32)

@@ -176,6 +176,9 @@ class gwnet(nn.Module):
         self.receptive_field = receptive_field
         self._statics = None
         self._statics_dev = None
+        # 'f32': exact fp32 MFMA everywhere (parity mode); 'bf16': bf16 operands / fp32 accumulate for the
+        # dense adaptive-adjacency products (throughput mode of BASELINE config 2)
+        self.dense_dtype = 'f32'
         self.to(device)
 
     # ------------------------------------------------------------------ engine plumbing
@@ -223,6 +226,7 @@ class gwnet(nn.Module):
                           gcn=self._use_gcn(), adaptive=self._use_gcn() and self.addaptadj,
                           dropout=self.dropout, names=names)
         cfg.grad_out = getattr(self, '_mo_grad_out', None)
+        cfg.dense_bf16 = (getattr(self, 'dense_dtype', 'f32') == 'bf16')
         bn_bufs = [(m.running_mean, m.running_var) for m in self.bn]
         if self.training:
             for m in self.bn:

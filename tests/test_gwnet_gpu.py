@@ -155,3 +155,27 @@ def test_gwnet_config2_shape_properties():
         ya = m(x)
         yb = m(x[:1])
     assert_close(ya[:1], yb, 1e-5, 1e-4, 'eval-mode batch independence')
+
+
+def test_gwnet_bf16_dense_mode_close_to_fp32():
+    """Throughput mode: bf16 operands (fp32 accumulate) for the dense adaptive-adjacency products only.
+    Stated tolerance vs the fp32 mode on the same inputs: 2e-2 of the output scale, loss within 1e-2
+    relative; gradients within 5e-2 of each tensor's scale."""
+    cfg = dict(B=2, N=304, T=12, in_dim=32, out_dim=12, K=2, nsup=2, seed=910, knn=(304, 1))
+    sup = _supports(cfg)
+    outs = {}
+    for mode in ('f32', 'bf16'):
+        m = _model(cfg, sup).train()
+        m.dense_dtype = mode
+        x = rand(911, (2, 32, 304, 12)).cuda().requires_grad_(True)
+        y = m(x)
+        loss = F.mse_loss(y, rand(912, tuple(y.shape)).cuda())
+        loss.backward()
+        outs[mode] = (y.detach(), loss.item(), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None})
+    y32, l32, g32 = outs['f32']
+    y16, l16, g16 = outs['bf16']
+    assert float((y16 - y32).abs().max()) <= 2e-2 * float(y32.abs().max())
+    assert abs(l16 - l32) <= 1e-2 * l32
+    for k in g32:
+        s = float(g32[k].abs().max())
+        assert float((g16[k] - g32[k]).abs().max()) <= 5e-2 * s + 1e-7, k

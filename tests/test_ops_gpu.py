@@ -415,3 +415,25 @@ def test_adam_step(L):
     L.call('mo_adam_step', L.ptr(p), L.ptr(dev(g)), L.ptr(m), L.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8,
            1 - 0.9, 1 - 0.999, 1.0, L.stream())
     close(p, pr.detach(), 1e-6, 'adam p')
+
+
+@pytest.mark.parametrize('M,N,K,krows', [(128, 128, 32, True), (3000, 512, 3000, True), (300, 256, 296, True),
+                                         (3000, 3000, 1024, False), (200, 136, 64, False)])
+def test_gemm_bf16(L, M, N, K, krows):
+    """bf16 operands / fp32 accumulate: exact up to fp32 summation order against an fp32 matmul of the
+    bf16-rounded operands; asymmetric data catches fragment-layout transpositions."""
+    A = rand(90, (M, K))
+    B = rand(91, (K, N)) if krows else rand(91, (N, K))
+    Ab = torch.empty(M, K, device='cuda', dtype=torch.bfloat16)
+    Bb = torch.empty(B.shape, device='cuda', dtype=torch.bfloat16)
+    L.call('mo_f32_to_bf16', L.ptr(dev(A)), L.ptr(Ab), A.numel(), L.stream())
+    L.call('mo_f32_to_bf16', L.ptr(dev(B)), L.ptr(Bb), B.numel(), L.stream())
+    assert torch.equal(Ab.cpu(), A.to(torch.bfloat16))            # RNE conversion matches torch
+    Ar, Br = A.to(torch.bfloat16).float(), B.to(torch.bfloat16).float()
+    ref = Ar @ (Br if krows else Br.t())
+    D0 = rand(92, (M, N))
+    for beta in (0, 1):
+        D = dev(D0.clone())
+        L.call('mo_gemm_bf16', L.ptr(Ab), K, L.ptr(Bb), N if krows else K, 1 if krows else 0, L.ptr(D), N, M, N, K,
+               beta, L.stream())
+        close(D, ref + (D0 if beta else 0), 2e-5, f'gemm_bf16 beta={beta}')
