@@ -35,6 +35,29 @@ static void epi_init(MoEpi& e, float* out, int ldo) {
   e.partial = nullptr; e.slab_stride = 0; e.kchunk = 0;
 }
 
+// The branch-free vector loader applies when every segment is 16-byte loadable, segments are 32/64 wide,
+// the row map shares one To, ReLU/dropout are operand-wide and the affine (if any) sits on 32-wide segments.
+static bool op_fast_ok(const MoOperand& o) {
+  if ((o.cols & 3) != 0) return false;
+  if (o.nseg > 1 && o.segw != 32 && o.segw != 64) return false;
+  for (int s = 0; s < o.nseg; ++s) {
+    const MoSeg& g = o.seg[s];
+    if (!g.ptr || (((uintptr_t)g.ptr) & 15) || (g.ld & 3)) return false;
+    if (g.To != o.seg[0].To || g.relu != o.seg[0].relu) return false;
+    if (g.scale && !(o.nseg == 1 ? o.cols <= 32 : o.segw == 32)) return false;
+    if (g.drop_thresh && o.nseg != 1) return false;
+    if (s > 0 && g.drop_thresh) return false;
+  }
+  return true;
+}
+// normalise the identity row map (To == 0) to To = Ti = 1, off = 0 for the fast loader
+static MoOperand op_norm(const MoOperand& o) {
+  MoOperand r = o;
+  for (int s = 0; s < r.nseg; ++s)
+    if (r.seg[s].To == 0) { r.seg[s].To = 1; r.seg[s].Ti = 1; r.seg[s].off = 0; }
+  return r;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int AM, int BMODE, int EPI>
 static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M, long N, int nz,
                   hipStream_t st) {
@@ -42,7 +65,14 @@ static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M
   dim3 grid(mo_cdiv(M, BM), mo_cdiv(N, BN), nz);
   dim3 block(WM * WN * 64);
   MoGeom G = {0, 0, 0, 1, 0, 0};
-  hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI>), grid, block, 0, st, A, B, E, G);
+  if (op_fast_ok(A) && op_fast_ok(B)) {
+    const MoOperand An = op_norm(A), Bn = op_norm(B);
+    hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI, MO_SRC_PLAIN, MO_SRC_PLAIN, 1>), grid,
+                       block, 0, st, An, Bn, E, G);
+  } else {
+    hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI, MO_SRC_PLAIN, MO_SRC_PLAIN, 0>), grid,
+                       block, 0, st, A, B, E, G);
+  }
   return mo_launch_status();
 }
 

@@ -84,6 +84,18 @@ struct MoEpi {
   int kchunk;              // split-K chunk (multiple of BK); 0: whole K
 };
 
+// Loads through descriptor pointers (which travel through LDS and lose their address space) must be
+// emitted as global_load, not flat_load: flat loads also count on lgkmcnt, so every LDS wait of the MFMA
+// phase would stall on the prefetch of the next tile.
+typedef float mo_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float mo_gload(const float* p) {
+  return *(const __attribute__((address_space(1))) float*)(uintptr_t)p;
+}
+__device__ __forceinline__ float4 mo_gload(const float4* p) {
+  const mo_v4f v = *(const __attribute__((address_space(1))) mo_v4f*)(uintptr_t)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ bool mo_seg_row(const MoSeg& s, int r, long& srow) {
   if (s.To == 0) { srow = r; return true; }
   int g = r / s.To;
@@ -93,7 +105,7 @@ __device__ __forceinline__ bool mo_seg_row(const MoSeg& s, int r, long& srow) {
 }
 
 __device__ __forceinline__ float mo_post(const MoSeg& s, float v, int cc, long srow) {
-  if (s.scale) v = v * s.scale[cc] + s.shift[cc];
+  if (s.scale) v = v * mo_gload(s.scale + cc) + mo_gload(s.shift + cc);
   if (s.relu) v = fmaxf(v, 0.f);
   if (s.drop_thresh) {
     uint32_t h = mo_hash32(s.drop_seed, (uint32_t)(srow * s.ld + cc));
@@ -115,12 +127,12 @@ __device__ __forceinline__ float4 mo_fetch4(const MoSeg* segs, int nseg, int seg
   const float* p = sg.ptr + srow * (long)sg.ld + cc;
   bool vec = ((sg.ld & 3) == 0) && ((((uintptr_t)sg.ptr) & 15) == 0) && (cc + 3 < w);
   if (vec) {
-    v = *reinterpret_cast<const float4*>(p);
+    v = mo_gload(reinterpret_cast<const float4*>(p));
   } else {
-    if (cc + 0 < w) v.x = p[0];
-    if (cc + 1 < w) v.y = p[1];
-    if (cc + 2 < w) v.z = p[2];
-    if (cc + 3 < w) v.w = p[3];
+    if (cc + 0 < w) v.x = mo_gload(p + 0);
+    if (cc + 1 < w) v.y = mo_gload(p + 1);
+    if (cc + 2 < w) v.z = mo_gload(p + 2);
+    if (cc + 3 < w) v.w = mo_gload(p + 3);
   }
   if (sg.scale || sg.relu || sg.drop_thresh) {
     if (cc + 0 < w) v.x = mo_post(sg, v.x, cc + 0, srow);
@@ -148,13 +160,13 @@ __device__ __forceinline__ float4 mo_fetch4_im2col(const MoSeg* segs, const MoGe
   const float* base = sg.ptr + (long)img * sg.ld + (long)c * g.HW + yy * g.W;
   float sc = 1.f, sh = 0.f;
   const bool aff = sg.scale != nullptr;
-  if (aff) { const int grp = img / g.gsize; sc = sg.scale[grp * Cs + c]; sh = sg.shift[grp * Cs + c]; }
+  if (aff) { const int grp = img / g.gsize; sc = mo_gload(sg.scale + grp * Cs + c); sh = mo_gload(sg.shift + grp * Cs + c); }
   float* vp = &v.x;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int xx = x + j + kx;
     if (xx >= 0 && xx < g.W) {
-      float t = base[xx];
+      float t = mo_gload(base + xx);
       if (aff) t = t * sc + sh;
       if (sg.relu) t = fmaxf(t, 0.f);
       vp[j] = t;
@@ -169,10 +181,10 @@ __device__ __forceinline__ float4 mo_fetch4_nchw(const MoSeg* segs, const MoGeom
   if (c >= rows || p >= cols) return v;
   const MoSeg& sg = segs[0];
   const int img = p / g.HW, pix = p - img * g.HW;
-  v = *reinterpret_cast<const float4*>(sg.ptr + (long)img * sg.ld + (long)c * g.HW + pix);
+  v = mo_gload(reinterpret_cast<const float4*>(sg.ptr + (long)img * sg.ld + (long)c * g.HW + pix));
   if (sg.scale) {
     const int grp = img / g.gsize;
-    const float sc = sg.scale[grp * g.C0 + c], sh = sg.shift[grp * g.C0 + c];
+    const float sc = mo_gload(sg.scale + grp * g.C0 + c), sh = mo_gload(sg.shift + grp * g.C0 + c);
     v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
   }
   if (sg.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -188,7 +200,7 @@ __device__ __forceinline__ float4 mo_fetch4_convt(const MoSeg* segs, const MoGeo
   const int img = p / g.HW, pix = p - img * g.HW;
   const int y = pix / g.W, x = pix - y * g.W;
   const float* base = sg.ptr + (long)img * sg.ld + (long)co * 4 * g.HW + (long)(2 * y + ky) * 2 * g.W + 2 * x + kx;
-  v.x = base[0]; v.y = base[2]; v.z = base[4]; v.w = base[6];
+  v.x = mo_gload(base); v.y = mo_gload(base + 2); v.z = mo_gload(base + 4); v.w = mo_gload(base + 6);
   return v;
 }
 
@@ -201,63 +213,136 @@ __device__ __forceinline__ float4 mo_fetch(const MoSeg* segs, int nseg, int segw
   return mo_fetch4(segs, nseg, segw, rows, cols, r, c);
 }
 
-template <int BX, int BK, int NT, int MODE, int SRC = MO_SRC_PLAIN>
-struct MoTile {
+// Tile loader.  FAST (plain sources whose segments are all 16-byte vector-loadable; checked on the host):
+// branch-free "issue" (address generation + unconditional clamped float4 loads, all in flight together)
+// and "finish" (zero-fill, folded affine / ReLU / dropout, LDS store) run on either side of the MFMA
+// phase, so a wave keeps NV independent loads outstanding instead of waiting for each one in turn.
+// Otherwise (odd leading dimensions, im2col / NCHW / convT-gather sources): generic element fetch.
+template <int BX, int BK, int NT, int MODE, int SRC, int FAST>
+struct MoLoader {
   static constexpr int PAD = (MODE == MO_KROWS) ? 4 : 1;
   static constexpr int LD = BX + PAD;
   static constexpr int NV = (BK * BX / 4) / NT;  // float4 per thread per tile
   static_assert((BK * BX / 4) % NT == 0, "tile/thread mismatch");
 
-  __device__ __forceinline__ static void load(float4 (&reg)[NV], const MoSeg* segs, int nseg, int segw,
-                                              int rows, int cols, const MoGeom& g, int x0, int k0, int tid) {
+  float4 reg[NV];
+  int meta[NV];        // FAST: (seg << 8 | col-in-seg) or -1 when the element is out of range / unmapped
+  uint32_t didx[NV];   // FAST: dropout element index (srow * ld + col)
+  int rg[NV], rt[NV];  // FAST + XROWS: hoisted row decomposition (rows are fixed over the k loop)
+
+  __device__ __forceinline__ void init(const MoOperand& op, int To, int x0, int tid) {
+    if (FAST && MODE == MO_XROWS) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int f = tid + i * NT;
-      if (MODE == MO_KROWS) {
-        int k = f / (BX / 4), x4 = f % (BX / 4);
-        reg[i] = mo_fetch<SRC>(segs, nseg, segw, rows, cols, g, k0 + k, x0 + 4 * x4);
-      } else {
-        int x = f / (BK / 4), k4 = f % (BK / 4);
-        reg[i] = mo_fetch<SRC>(segs, nseg, segw, rows, cols, g, x0 + x, k0 + 4 * k4);
+      for (int i = 0; i < NV; ++i) {
+        const int r = x0 + (tid + i * NT) / (BK / 4);
+        const int g = r / To;
+        rg[i] = g; rt[i] = r - g * To;
       }
     }
   }
-  __device__ __forceinline__ static void store(const float4 (&reg)[NV], float* T, int tid) {
+
+  __device__ __forceinline__ void issue(const MoSeg* segs, const MoOperand& op, int To, int segshift,
+                                        const MoGeom& G, int x0, int k0, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int f = tid + i * NT;
-      if (MODE == MO_KROWS) {
-        int k = f / (BX / 4), x4 = f % (BX / 4);
-        *reinterpret_cast<float4*>(&T[k * LD + 4 * x4]) = reg[i];
+      const int f = tid + i * NT;
+      int r, c;
+      if (MODE == MO_KROWS) { r = k0 + f / (BX / 4); c = x0 + 4 * (f % (BX / 4)); }
+      else { r = x0 + f / (BK / 4); c = k0 + 4 * (f % (BK / 4)); }
+      if (FAST) {
+        int g, t;
+        if (MODE == MO_XROWS) { g = rg[i]; t = rt[i]; }
+        else { g = r / To; t = r - g * To; }
+        // columns past the last segment (tile padding) are clamped onto it and masked by `valid`
+        const int s = (op.nseg > 1) ? min(c >> segshift, op.nseg - 1) : 0;
+        const int cc = (op.nseg > 1) ? (c & ((1 << segshift) - 1)) : c;
+        const MoSeg& sg = segs[s];
+        const float* bptr = sg.ptr;                 // read every descriptor field unconditionally:
+        const int sld = sg.ld, sTi = sg.Ti, soff = sg.off;   // no short-circuit => straight-line code
+        const int tt = t + soff;
+        const bool valid = (r < op.rows) & (c < op.cols) & ((unsigned)tt < (unsigned)sTi);
+        const long srow = (long)g * sTi + tt;
+        const long eoff = valid ? srow * (long)sld + cc : 0;
+        reg[i] = mo_gload(reinterpret_cast<const float4*>(bptr + eoff));
+        meta[i] = valid ? ((s << 8) | cc) : -1;
+        didx[i] = (uint32_t)eoff;
       } else {
-        int x = f / (BK / 4), k4 = f % (BK / 4);
-        T[(4 * k4 + 0) * LD + x] = reg[i].x;
-        T[(4 * k4 + 1) * LD + x] = reg[i].y;
-        T[(4 * k4 + 2) * LD + x] = reg[i].z;
-        T[(4 * k4 + 3) * LD + x] = reg[i].w;
+        reg[i] = mo_fetch<SRC>(segs, op.nseg, op.segw, op.rows, op.cols, G, r, c);
+      }
+    }
+  }
+
+  // aff: LDS table [seg][3][32]: scale, shift (identity when absent), unused
+  __device__ __forceinline__ void finish(float* T, const float* aff, const MoSeg* segs, int post, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT;
+      float4 v = reg[i];
+      if (FAST) {
+        const int m = meta[i];
+        if (post & 1) {       // folded BatchNorm affine (32-wide segments)
+          const int mm = m < 0 ? 0 : m;
+          const int s = (mm >> 8) & 7, cc = mm & 31;
+          const float4 sc = *reinterpret_cast<const float4*>(&aff[(s * 2 + 0) * 32 + cc]);
+          const float4 sh = *reinterpret_cast<const float4*>(&aff[(s * 2 + 1) * 32 + cc]);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+        if (post & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (post & 4) {       // regenerated dropout mask (single-segment operands)
+          const MoSeg& sg = segs[0];
+          float* vp = &v.x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t h = mo_hash32(sg.drop_seed, didx[i] + q);
+            vp[q] = (h >= sg.drop_thresh) ? vp[q] * sg.drop_scale : 0.f;
+          }
+        }
+        if (m < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (MODE == MO_KROWS) {
+        const int k = f / (BX / 4), x4 = f % (BX / 4);
+        *reinterpret_cast<float4*>(&T[k * LD + 4 * x4]) = v;
+      } else {
+        const int x = f / (BK / 4), k4 = f % (BK / 4);
+        T[(4 * k4 + 0) * LD + x] = v.x;
+        T[(4 * k4 + 1) * LD + x] = v.y;
+        T[(4 * k4 + 2) * LD + x] = v.z;
+        T[(4 * k4 + 3) * LD + x] = v.w;
       }
     }
   }
 };
 
+// per-operand LDS affine table [seg][2][32] (scale | shift); identity for segments without an affine
+__device__ __forceinline__ void mo_fill_aff(float* aff, const MoOperand& op, int tid, int nthreads) {
+  for (int i = tid; i < MO_MAX_SEG * 64; i += nthreads) {
+    const int s = i >> 6, which = (i >> 5) & 1, c = i & 31;
+    float v = which ? 0.f : 1.f;
+    if (s < op.nseg && op.seg[s].scale) v = which ? op.seg[s].shift[c] : op.seg[s].scale[c];
+    aff[i] = v;
+  }
+}
+
 __device__ __forceinline__ float mo_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI, int ASRC = MO_SRC_PLAIN,
-          int BSRC = MO_SRC_PLAIN>
+          int BSRC = MO_SRC_PLAIN, int FAST = 0>
 __global__ void __launch_bounds__(WM* WN * 64)
 mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom G) {
   constexpr int NT = WM * WN * 64;
   constexpr int SM = BM / WM, SN = BN / WN;
   constexpr int TM = SM / 32, TN = SN / 32;
   static_assert(SM % 32 == 0 && SN % 32 == 0, "wave tile must be a multiple of 32x32");
-  using TA = MoTile<BM, BK, NT, AMODE, ASRC>;
-  using TB = MoTile<BN, BK, NT, BMODE, BSRC>;
+  using TA = MoLoader<BM, BK, NT, AMODE, ASRC, FAST>;
+  using TB = MoLoader<BN, BK, NT, BMODE, BSRC, FAST>;
 
   __shared__ __attribute__((aligned(16))) float As[2][BK * TA::LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * TB::LD];
   __shared__ MoSeg sA[MO_MAX_SEG];
   __shared__ MoSeg sB[MO_MAX_SEG];
   __shared__ float red[(EPI == MO_EPI_MLP) ? WM * WN * 64 : 1];
+  __shared__ __attribute__((aligned(16))) float affA[FAST ? MO_MAX_SEG * 64 : 4];
+  __shared__ __attribute__((aligned(16))) float affB[FAST ? MO_MAX_SEG * 64 : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -269,6 +354,22 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
 
   // stage operand descriptors in LDS (segment index may vary per lane)
   if (tid < MO_MAX_SEG) { sA[tid] = A.seg[tid]; sB[tid] = B.seg[tid]; }
+  // FAST path, uniform per operand: bit0 affine present, bit1 ReLU, bit2 dropout
+  int postA = 0, postB = 0;
+  if (FAST) {
+    for (int q = 0; q < MO_MAX_SEG; ++q) {
+      if (q < A.nseg && A.seg[q].scale) postA |= 1;
+      if (q < B.nseg && B.seg[q].scale) postB |= 1;
+    }
+    if (A.seg[0].relu) postA |= 2;
+    if (B.seg[0].relu) postB |= 2;
+    if (A.seg[0].drop_thresh) postA |= 4;
+    if (B.seg[0].drop_thresh) postB |= 4;
+    if (postA & 1) mo_fill_aff(affA, A, tid, NT);
+    if (postB & 1) mo_fill_aff(affB, B, tid, NT);
+  }
+  const int ToA = A.seg[0].To > 0 ? A.seg[0].To : 1, ToB = B.seg[0].To > 0 ? B.seg[0].To : 1;
+  const int shA = (A.segw == 64) ? 6 : 5, shB = (B.segw == 64) ? 6 : 5;
   __syncthreads();
 
   // logical extents: M, N from the x-direction of each operand, K from the k-direction
@@ -278,7 +379,6 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
     kbeg = blockIdx.z * E.kchunk;
     kend = min(K, kbeg + E.kchunk);
   }
-  const int a_rows = A.rows, a_cols = A.cols, b_rows = B.rows, b_cols = B.cols;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -288,15 +388,18 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[TA::NV], rb[TB::NV];
+  TA la;
+  TB lb;
+  la.init(A, ToA, m0, tid);
+  lb.init(B, ToB, n0, tid);
   const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-  // Bound the k direction by kend as well (split-K chunks end on BK multiples except the last,
-  // which ends at K == rows/cols, so the operand's own extent check is sufficient).
+  // Split-K chunks end on BK multiples except the last, which ends at K == rows/cols, so the operand's
+  // own extent check bounds the k direction.
   if (nk > 0) {
-    TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, G, m0, kbeg, tid);
-    TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, G, n0, kbeg, tid);
-    TA::store(ra, As[0], tid);
-    TB::store(rb, Bs[0], tid);
+    la.issue(sA, A, ToA, shA, G, m0, kbeg, tid);
+    lb.issue(sB, B, ToB, shB, G, n0, kbeg, tid);
+    la.finish(As[0], affA, sA, postA, tid);
+    lb.finish(Bs[0], affB, sB, postB, tid);
   }
   __syncthreads();
 
@@ -304,8 +407,8 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      TA::load(ra, sA, A.nseg, A.segw, a_rows, a_cols, G, m0, kbeg + (kt + 1) * BK, tid);
-      TB::load(rb, sB, B.nseg, B.segw, b_rows, b_cols, G, n0, kbeg + (kt + 1) * BK, tid);
+      la.issue(sA, A, ToA, shA, G, m0, kbeg + (kt + 1) * BK, tid);
+      lb.issue(sB, B, ToB, shB, G, n0, kbeg + (kt + 1) * BK, tid);
     }
     const float* Ac = As[cur];
     const float* Bc = Bs[cur];
@@ -323,8 +426,8 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      TA::store(ra, As[cur ^ 1], tid);
-      TB::store(rb, Bs[cur ^ 1], tid);
+      la.finish(As[cur ^ 1], affA, sA, postA, tid);
+      lb.finish(Bs[cur ^ 1], affB, sB, postB, tid);
     }
     __syncthreads();
   }
