@@ -4,6 +4,7 @@
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
+#define RED_STAGE 32   // stage-A width of the two-stage [nblk][64] -> [64] reductions
 
 // ------------------------------------------------------------------------------------------------
 // GEMM launch helpers
@@ -32,7 +33,7 @@ static void epi_init(MoEpi& e, float* out, int ldo) {
   e.add = nullptr; e.ldadd = 0; e.aTo = 0; e.aTi = 0; e.aoff = 0; e.ascale = nullptr; e.ashift = nullptr;
   e.aux = nullptr; e.ldaux = 0;
   e.drop_seed = 0; e.drop_thresh = 0; e.drop_scale = 1.f;
-  e.partial = nullptr; e.slab_stride = 0; e.kchunk = 0;
+  e.partial = nullptr; e.slab_stride = 0; e.kchunk = 0; e.colsum = nullptr;
 }
 
 // The branch-free vector loader applies when every segment is 16-byte loadable, segments are 32/64 wide,
@@ -81,9 +82,9 @@ static void wgrad_plan(int M, int N, long P, int& nsplit, int& kchunk) {
   const int BK = 32;
   long tiles = (P + BK - 1) / BK;
   long tmn = (long)mo_cdiv(M, 64) * mo_cdiv(N, 64);
-  long want = 2048 / tmn;              // ~2048 blocks in flight (>> 256 CUs), slabs stay small
+  long want = 768 / tmn;               // ~3 blocks per CU in flight; fewer, longer K-slices keep the slabs small
   if (want < 1) want = 1;
-  if (want > 1024) want = 1024;
+  if (want > 512) want = 512;
   long per = (tiles + want - 1) / want;
   if (per < 4) per = 4;                // at least 128 rows per slice
   kchunk = (int)(per * BK);
@@ -93,7 +94,9 @@ static void wgrad_plan(int M, int N, long P, int& nsplit, int& kchunk) {
 
 extern "C" long mo_wgrad_ws_floats(int M, int N, long P) {
   int ns, kc; wgrad_plan(M, N, P, ns, kc);
-  return (long)ns * M * N + 16;
+  long a = (long)ns * M * N + (long)ns * M + 64;          // slabs + fused column-sum slabs
+  long b = (long)mo_cdiv(P, 512) * (M > N ? M : N) + 64;  // fallback column-sum partials
+  return a > b ? a : b;
 }
 
 // out[i] (=) sum_z slab[z][i]: 32 outputs x 8 z-lanes per block, fixed summation order (deterministic)
@@ -264,18 +267,25 @@ extern "C" int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const floa
   return launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, 1, ST(stream));
 }
 
-// generic weight-gradient: slab[z][M][N] = sum_{k in chunk z} A(k,m) B(k,n), then reduce
-static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int N, float* ws, float* dW,
-                     hipStream_t st) {
+// generic weight-gradient: slab[z][M][N] = sum_{k in chunk z} A(k,m) B(k,n), then reduce.  When `db` is
+// given, the column sums of A (the bias gradient) are produced by the same pass (fast loader) or by a
+// separate column-sum kernel over `a_plain` [P][M] (generic loader; a_plain may be null if impossible).
+static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int N, float* ws, float* dW, float* db,
+                     hipStream_t st, bool* db_done = nullptr) {
   int nsplit, kchunk; wgrad_plan(M, N, P, nsplit, kchunk);
   MoEpi E; epi_init(E, ws, N);
   E.slab_stride = (long)M * N; E.kchunk = kchunk;
+  const bool fused = db && op_fast_ok(A) && op_fast_ok(Bo);
+  float* cs = ws + (long)nsplit * M * N;
+  if (fused) E.colsum = cs;
   int rc = launch<64, 64, 32, 2, 2, MO_KROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, M, N, nsplit, st);
   if (rc) return rc;
   if (dW) {
     long n = (long)M * N;
     hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(n), dim3(256), 0, st, ws, n, nsplit, dW, n);
   }
+  if (fused) hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(M), dim3(256), 0, st, cs, (long)M, nsplit, db, (long)M);
+  if (db_done) *db_done = fused;
   return mo_launch_status();
 }
 
@@ -285,9 +295,10 @@ extern "C" int mo_conv1x1_bwd_weight(const float* dout, int Co, long P, const fl
   MoOperand A = op_simple(dout, Co, P, Co);   // KROWS: rows = k = p, cols = m = co
   MoOperand Bo = op_simple(in, Ci, P, Ci);    // KROWS: rows = k = p (mapped), cols = n = ci
   Bo.seg[0].To = To; Bo.seg[0].Ti = Ti; Bo.seg[0].off = off; Bo.seg[0].relu = in_relu;
-  int rc = wgrad_run(A, Bo, P, Co, Ci, ws, dW, ST(stream));
+  bool done = false;
+  int rc = wgrad_run(A, Bo, P, Co, Ci, ws, dW, db, ST(stream), &done);
   if (rc) return rc;
-  if (db) return mo_colsum(dout, P, Co, db, ws, stream);   // ws reuse is stream-ordered after the reduce
+  if (db && !done) return mo_colsum(dout, P, Co, db, ws, stream);   // ws reuse is stream-ordered after the reduce
   return MO_OK;
 }
 
@@ -503,18 +514,23 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
       B3.seg[t].To = Tout; B3.seg[t].Ti = Tin; B3.seg[t].off = t * dil;
       B3.seg[t].scale = scale; B3.seg[t].shift = shift;
     }
-    rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, st);
+    // bias gradients = column sums of dpre (64 columns), fused into the same pass: [dbf | dbg]
+    float* db64 = ws2 + mo_wgrad_ws_floats(64, 32 * K, Pout) - 64;
+    bool done = false;
+    rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, db64, st, &done);
     if (rc) return rc;
     int nsplit, kchunk; wgrad_plan(64, 32 * K, Pout, nsplit, kchunk);
     hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(mo_cdiv(64 * 32 * K, 32)), dim3(256), 0, st, ws2,
                        (long)64 * 32 * K, nsplit, K, dWf, dWg);
-  }
-  // 4) bias gradients: column sums of dpre (64 columns) -> [dbf | dbg] via ws2 (stream ordered)
-  {
-    int nb = mo_cdiv(Pout, CS_ROWS);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, dpre_ws, Pout, 64, ws2);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, ws2, (long)64, nb, dbf, (long)32);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, ws2 + 32, (long)64, nb, dbg, (long)32);
+    if (done) {
+      (void)hipMemcpyAsync(dbf, db64, 32 * sizeof(float), hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(dbg, db64 + 32, 32 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    } else {
+      int nb = mo_cdiv(Pout, CS_ROWS);
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, dpre_ws, Pout, 64, ws2);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, ws2, (long)64, nb, dbf, (long)32);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, ws2 + 32, (long)64, nb, dbg, (long)32);
+    }
   }
   return mo_launch_status();
 }
@@ -569,7 +585,7 @@ extern "C" int mo_adj_grad(const float* X, const float* dY, int N, long J, float
 // ------------------------------------------------------------------------------------------------
 // gcn mlp + residual + BatchNorm
 // ------------------------------------------------------------------------------------------------
-extern "C" long mo_mlp_partial_floats(long P) { return (long)mo_cdiv(P, 128) * 64 + 64; }
+extern "C" long mo_mlp_partial_floats(long P) { return ((long)mo_cdiv(P, 128) + RED_STAGE + 2) * 64; }
 
 extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, const float* b, long G, int Tout,
                               int Tin, const float* res, const float* rscale, const float* rshift,
@@ -589,6 +605,18 @@ extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, 
   E.drop_seed = drop_seed; E.drop_thresh = drop_thresh; E.drop_scale = drop_scale;
   E.partial = partial;
   return launch<128, 32, 32, 4, 1, MO_XROWS, MO_XROWS, MO_EPI_MLP>(A, Bo, E, P, 32, 1, ST(stream));
+}
+
+// stage A of every [nblk][64] -> [64] reduction: 32 blocks each sum a strided share of the rows
+// (coalesced 256-byte rows), fixed order => deterministic
+__global__ void rows64_reduce_kernel(const float* __restrict__ part, long nblk, float* __restrict__ out /* [RED_STAGE][64] */) {
+  __shared__ double sm[4][64];
+  const int c = threadIdx.x & 63, y = threadIdx.x >> 6;   // 256 threads: 4 row lanes x 64 columns
+  double s = 0.0;
+  for (long b = (long)blockIdx.x * 4 + y; b < nblk; b += (long)RED_STAGE * 4) s += (double)part[b * 64 + c];
+  sm[y][c] = s;
+  __syncthreads();
+  if (y == 0) out[blockIdx.x * 64 + c] = (float)(sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c]);
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, long nblk, long count, const float* gamma,
@@ -631,6 +659,12 @@ extern "C" int mo_bn_finalize(const float* partial, long nblk, long count, const
                               float* scale, float* shift, float* mean, float* rstd, void* stream) {
   MO_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && mean && rstd && count > 0);
   MO_CHECK_ARG(!training || (partial && nblk > 0));
+  if (training && nblk > 4 * RED_STAGE) {
+    // the partial buffer has 64 spare floats... use its tail rows [nblk .. nblk+RED_STAGE) as stage-A output
+    float* stage = const_cast<float*>(partial) + nblk * 64;
+    hipLaunchKernelGGL(rows64_reduce_kernel, dim3(RED_STAGE), dim3(256), 0, ST(stream), partial, nblk, stage);
+    partial = stage; nblk = RED_STAGE;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(512), 0, ST(stream), partial, nblk, count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd);
   return mo_launch_status();
@@ -700,7 +734,13 @@ extern "C" int mo_bn_bwd(const float* dy, const float* h, long P, const float* g
   const long nblk = mo_cdiv(P, 128);
   float* k12 = ws + nblk * 64;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, st, dy, h, P, mean, rstd, ws);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(512), 0, st, ws, nblk, dgamma, dbeta, k12, P);
+  if (nblk > 4 * RED_STAGE) {
+    float* stage = ws + (nblk + 1) * 64;
+    hipLaunchKernelGGL(rows64_reduce_kernel, dim3(RED_STAGE), dim3(256), 0, st, ws, nblk, stage);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(512), 0, st, stage, (long)RED_STAGE, dgamma, dbeta, k12, P);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(512), 0, st, ws, nblk, dgamma, dbeta, k12, P);
+  }
   const long n4 = P * 8;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(mo_cdiv(n4, 256)), dim3(256), 0, st, (const float4*)dy,
                      (const float4*)h, n4, gamma, mean, rstd, k12, (float4*)dh);
@@ -755,8 +795,10 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
   MoOperand B2; op_init(B2);
   B2.nseg = ns; B2.segw = 32; B2.rows = (int)P; B2.cols = 32 * ns;
   for (int s = 0; s < ns; ++s) seg_init(B2.seg[s], srcs[s], 32);
-  rc = wgrad_run(A2, B2, P, 32, 32 * ns, ws, dW, st);
+  bool done = false;
+  rc = wgrad_run(A2, B2, P, 32, 32 * ns, ws, dW, db, st, &done);
   if (rc) return rc;
+  if (done) return MO_OK;
   // bias: db[co] = sum_p dm[p][co]  (dropout mask applies) -> reuse the GEMM with a ones column is
   // overkill; compute via colsum on dm materialised?  dm == dh when dropout is off; with dropout the
   // mask must be applied, so use a dedicated kernel below.

@@ -82,6 +82,7 @@ struct MoEpi {
   float* partial;          // MLP: per-block BatchNorm partial sums [gridDim.x][64] (sum | sumsq)
   long slab_stride;        // split-K: slab z goes to out + z*slab_stride
   int kchunk;              // split-K chunk (multiple of BK); 0: whole K
+  float* colsum;           // FAST, A in KROWS mode: per-slice column sums of A, [gridDim.z][M] (bias gradient)
 };
 
 // Loads through descriptor pointers (which travel through LDS and lose their address space) must be
@@ -229,8 +230,11 @@ struct MoLoader {
   int meta[NV];        // FAST: (seg << 8 | col-in-seg) or -1 when the element is out of range / unmapped
   uint32_t didx[NV];   // FAST: dropout element index (srow * ld + col)
   int rg[NV], rt[NV];  // FAST + XROWS: hoisted row decomposition (rows are fixed over the k loop)
+  float4 cs[NV];       // FAST + KROWS: running column sums of the tile (fused bias gradient), post bit 3
 
   __device__ __forceinline__ void init(const MoOperand& op, int To, int x0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (FAST && MODE == MO_XROWS) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -298,6 +302,7 @@ struct MoLoader {
           }
         }
         if (m < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == MO_KROWS && (post & 8)) { cs[i].x += v.x; cs[i].y += v.y; cs[i].z += v.z; cs[i].w += v.w; }
       }
       if (MODE == MO_KROWS) {
         const int k = f / (BX / 4), x4 = f % (BX / 4);
@@ -364,6 +369,7 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
     if (A.seg[0].relu) postA |= 2;
     if (B.seg[0].relu) postB |= 2;
     if (A.seg[0].drop_thresh) postA |= 4;
+    if (AMODE == MO_KROWS && E.colsum && blockIdx.y == 0) postA |= 8;
     if (B.seg[0].drop_thresh) postB |= 4;
     if (postA & 1) mo_fill_aff(affA, A, tid, NT);
     if (postB & 1) mo_fill_aff(affB, B, tid, NT);
@@ -428,6 +434,27 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
     if (kt + 1 < nk) {
       la.finish(As[cur ^ 1], affA, sA, postA, tid);
       lb.finish(Bs[cur ^ 1], affB, sB, postB, tid);
+    }
+    __syncthreads();
+  }
+
+  if (FAST && AMODE == MO_KROWS && (postA & 8)) {
+    // column sums of A over this block's K range: threads with equal x4 hold partial sums of the same
+    // four columns; reduce the NT/(BM/4) k-lanes through LDS (the tile buffers are free now)
+    constexpr int XG = BM / 4, KL = NT / XG;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TA::NV; ++i) { t.x += la.cs[i].x; t.y += la.cs[i].y; t.z += la.cs[i].z; t.w += la.cs[i].w; }
+    float* red2 = &As[0][0];
+    const int x4 = tid % XG, kl = tid / XG;
+    *reinterpret_cast<float4*>(&red2[kl * BM + 4 * x4]) = t;
+    __syncthreads();
+    if (tid < BM) {
+      float sacc = 0.f;
+#pragma unroll 4
+      for (int q = 0; q < KL; ++q) sacc += red2[q * BM + tid];
+      const int Mtot = A.cols;
+      if (m0 + tid < Mtot) E.colsum[(long)blockIdx.z * Mtot + m0 + tid] = sacc;
     }
     __syncthreads();
   }
