@@ -538,20 +538,30 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
 // ------------------------------------------------------------------------------------------------
 // node-axis products
 // ------------------------------------------------------------------------------------------------
+// One block per (output row, 256-float4 chunk of the row): the edge loop is unrolled by 4 with clamped
+// indices and zero weights so that four independent 16-byte gathers are in flight per thread.
 __global__ void spmm_csr_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                 const float* __restrict__ vals, const float4* __restrict__ X, float4* __restrict__ Y,
                                 long J4, int beta) {
   const int row = blockIdx.x;
+  const long j = (long)blockIdx.y * blockDim.x + threadIdx.x;
+  if (j >= J4) return;
   const int e0 = rowptr[row], e1 = rowptr[row + 1];
-  for (long j = threadIdx.x; j < J4; j += blockDim.x) {
-    float4 acc = beta ? Y[(long)row * J4 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = e0; e < e1; ++e) {
-      const float a = vals[e];
-      const float4 x = X[(long)colidx[e] * J4 + j];
-      acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w;
+  float4 acc = beta ? Y[(long)row * J4 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = e0; e < e1; e += 4) {
+    float a[4]; float4 x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ee = min(e + q, e1 - 1);
+      a[q] = (e + q < e1) ? vals[ee] : 0.f;
+      x[q] = X[(long)colidx[ee] * J4 + j];
     }
-    Y[(long)row * J4 + j] = acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc.x += a[q] * x[q].x; acc.y += a[q] * x[q].y; acc.z += a[q] * x[q].z; acc.w += a[q] * x[q].w;
+    }
   }
+  Y[(long)row * J4 + j] = acc;
 }
 extern "C" int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const float* vals, int n_rows,
                            const float* X, float* Y, long J, int beta, void* stream) {
@@ -559,7 +569,7 @@ extern "C" int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const f
   MO_CHECK_ARG((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 15) == 0);
   long J4 = J / 4;
   int bs = J4 >= 256 ? 256 : (J4 >= 128 ? 128 : 64);
-  hipLaunchKernelGGL(spmm_csr_kernel, dim3(n_rows), dim3(bs), 0, ST(stream), rowptr, colidx, vals,
+  hipLaunchKernelGGL(spmm_csr_kernel, dim3(n_rows, mo_cdiv(J4, bs)), dim3(bs), 0, ST(stream), rowptr, colidx, vals,
                      (const float4*)X, (float4*)Y, J4, beta);
   return mo_launch_status();
 }

@@ -1,0 +1,61 @@
+"""Secondary measurement: Modified_UNET training tiles/s (fwd + MSE + bwd + Adam) on the HIP path.
+  python tools/bench_unet.py [--batch 2 --horizon 7 --size 128 --cin 1 --steps 5]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--horizon', type=int, default=7)
+    ap.add_argument('--size', type=int, default=128)
+    ap.add_argument('--cin', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    a = ap.parse_args()
+    import multimodal_outage_amd._lib as L
+    L.load()
+    from multimodal_outage_amd.models.unet import Modified_UNET
+    from multimodal_outage_amd.lit import mse_and_metrics
+    from multimodal_outage_amd.trainer import FlatTrainer
+    torch.manual_seed(42)
+    m = Modified_UNET('gwnet', a.horizon, input_channels=a.cin, output_channels=a.cin, image_dimension=a.size).cuda().train()
+    tr = FlatTrainer(m)
+    B, H, S = a.batch, a.horizon, a.size
+    x = torch.randn(B, 67, H, a.cin, S, S, device='cuda')
+    y = torch.randn(B, 67, H, a.cin, S, S, device='cuda')
+    td = torch.randn(B, 67, H, 64, device='cuda')
+
+    def step():
+        tr.zero_grad()
+        out = m(x, td)
+        loss, _, _, _ = mse_and_metrics(out, y)
+        loss.backward()
+        tr.allreduce()
+        tr.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tiles = B * 67 * H * a.steps
+    print(json.dumps({"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(tiles / dt, 1), "unit": "tiles/s",
+                      "ms_per_step": round(dt / a.steps * 1e3, 2), "tiles_per_step": B * 67 * H,
+                      "config": {"batch": B, "horizon": H, "tile": f"{a.cin}x{S}x{S}", "counties": 67},
+                      "loss": round(float(loss), 5), "dtype": "f32"}))
+
+
+if __name__ == '__main__':
+    main()
