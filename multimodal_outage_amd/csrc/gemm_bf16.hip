@@ -37,7 +37,18 @@ gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__
   __shared__ __attribute__((aligned(16))) short Bs[2][B_KROWS ? GB_BK * GB_LDB : GB_BN * GB_LDA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int m0 = blockIdx.x * GB_BM, n0 = blockIdx.y * GB_BN;
+  // XCD-aware tile placement (speed only, any placement is correct): workgroups are dealt round-robin
+  // over the 8 XCDs, each with a private 4 MiB L2.  XCD x = b % 8 owns the (x % 2, x / 2) patch of a
+  // 2 x 4 split of the tile grid and walks it m-fastest, so that the ~128 co-resident workgroups of an
+  // XCD share A row-panels and B column-panels through its L2 instead of every XCD streaming all of B.
+  const int gm = (M + GB_BM - 1) / GB_BM, gn = (N + GB_BN - 1) / GB_BN;
+  const int pm = (gm + 1) / 2, pn = (gn + 3) / 4;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, idx = b >> 3;
+  const int lm = idx % pm, ln = idx / pm;
+  const int tm = (xcd & 1) * pm + lm, tn = (xcd >> 1) * pn + ln;
+  if (tm >= gm || tn >= gn || ln >= pn) return;     // padding of the patch grid (whole workgroup exits)
+  const int m0 = tm * GB_BM, n0 = tn * GB_BN;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -150,7 +161,8 @@ extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int 
   // 16-byte chunk loads: leading dimensions and the contiguous extents must be multiples of 8 elements
   MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (K % 8) == 0 && (!b_krows || (N % 8) == 0));
   MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
-  dim3 grid(mo_cdiv(M, GB_BM), mo_cdiv(N, GB_BN));
+  const int gm = mo_cdiv(M, GB_BM), gn = mo_cdiv(N, GB_BN);
+  dim3 grid(8 * ((gm + 1) / 2) * ((gn + 3) / 4));
   if (b_krows)
     hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)A, lda,
                        (const short*)B, ldb, D, ldd, M, N, K, beta);
