@@ -90,6 +90,12 @@ int mo_adj_grad(const float* X, const float* dY, int N, long J, float* dA, int b
 int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
                  int N, int K, int beta, void* stream);
 int mo_f32_to_bf16(const float* x, void* y, long n, void* stream);
+/* 256x256x32-tile variant with a 4-stage LDS-DMA ring (three k-tiles in flight): same contract, plus: A must be
+ * readable and zero in columns [K, a_kpad) with a_kpad >= K rounded up to 32 (mo_f32_to_bf16_padded makes such
+ * a copy); K % 32 == 0 when b_krows == 0. */
+int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
+                     int ldd, int M, int N, int K, int beta, void* stream);
+int mo_f32_to_bf16_padded(const float* x, int rows, int cols, void* y, int ld_out, void* stream);
 
 /* ---- gcn mlp + dropout + residual + BatchNorm statistics (graph_wavenet.py:95-97,247,250) -------
  * h[p][:] = drop(W @ cat[srcs[0..ns)][p] + b) + (res[(g,t+Tin-Tout)]*rscale+rshift); per-block BN

@@ -193,3 +193,209 @@ extern "C" int mo_f32_to_bf16(const float* x, void* y, long n, void* stream) {
                      (uint4*)y, n8);
   return mo_launch_status();
 }
+
+// ================================================================================================
+// 256x256x32 tile, 8 waves (2x4 of 128x64), 4-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4)
+// with three k-tiles in flight behind counted vmcnt waits and one raw s_barrier per k-tile.
+//   throughput model of the 128^2 kernel above: (bytes in flight per CU) x (flop per byte of the tile)
+//   / (L2/MALL latency) -- 64 KB x 64 flop/B / ~2.4 us x 256 CUs ~ 0.45 PF, which is what it measures.
+//   This kernel has 96 KB in flight at 128 flop/B.
+// LDS images are unpadded and XOR-swizzled through the per-lane SOURCE address (the DMA destination is
+// wave-uniform base + lane*16):  [x][64 B] tiles: slot ^= (x>>2)&3 (conflict-free ds_read_b128);
+// [k][512 B] tiles: slot16 ^= (k&3)<<2 (conflict-free ds_read_b64_tr_b16).
+// Requirements (checked on the host): lda,ldb % 8 == 0; A readable and zero in columns [K, Kpad32) when
+// K % 32 != 0 (B rows are clamped, so 0 x finite = 0); N % 8 == 0 for KROWS B.
+// ================================================================================================
+typedef __attribute__((address_space(3))) void* gb_lds_ptr;
+typedef __attribute__((address_space(1))) const void* gb_g_ptr;
+
+// LDS-DMA issued from inline asm so that hipcc neither counts it in its own vmcnt bookkeeping nor drains
+// it (vmcnt(0)) in front of every LDS read of the ring; completion is tracked by the hand-counted
+// s_waitcnt vmcnt(N) of the k loop.  M0 (LDS destination base) is saved and restored in the same statement.
+__device__ __forceinline__ void gb_dma16(const void* gsrc, uint32_t lds_byte_off) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_byte_off)
+               : "memory");
+}
+
+#define G2_BM 256
+#define G2_BN 256
+#define G2_BK 32
+#define G2_ST 4
+#define G2_STAGE_SHORTS 16384   // 16 KB A + 16 KB B per stage, in bf16 elements
+
+template <bool B_KROWS>
+__global__ void __launch_bounds__(512)
+gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ D,
+                     int ldd, int M, int N, int K, int beta) {
+  __shared__ __attribute__((aligned(16))) short lds[G2_ST * G2_STAGE_SHORTS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+  const int gm = (M + G2_BM - 1) / G2_BM, gn = (N + G2_BN - 1) / G2_BN;
+  const int pm = (gm + 1) / 2, pn = (gn + 3) / 4;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int lm = idx % pm, ln = idx / pm;
+  const int tmi = (xcd & 1) * pm + lm, tni = (xcd >> 1) * pn + ln;
+  if (tmi >= gm || tni >= gn || ln >= pn) return;
+  const int m0 = tmi * G2_BM, n0 = tni * G2_BN;
+
+  // per-lane DMA source offsets (constant over k): two A and two B instructions per wave per stage
+  long a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = wave * 128 + i * 64 + lane;            // 16-byte slot index inside the 16 KB operand stage
+    {
+      const int x = p >> 2, pc = p & 3;
+      const int c = pc ^ ((x >> 2) & 3);
+      const int gr = min(m0 + x, M - 1);
+      a_off[i] = (long)gr * lda + 8 * c;
+    }
+    if (B_KROWS) {
+      const int kr = p >> 5, ph = p & 31;
+      const int lg = ph ^ ((kr & 3) << 2);
+      const int gc = min(n0 + 8 * lg, N - 8);
+      b_off[i] = gc;                                      // + (k0 + kr) * ldb at issue time (row clamp)
+    } else {
+      const int x = p >> 2, pc = p & 3;
+      const int c = pc ^ ((x >> 2) & 3);
+      const int gr = min(n0 + x, N - 1);
+      b_off[i] = (long)gr * ldb + 8 * c;
+    }
+  }
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) short*)lds;
+  auto issue = [&](int kt) {
+    const int k0 = kt * G2_BK;
+    const uint32_t st = lds_base + (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);   // byte offset of the stage
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int slot0 = wave * 128 + i * 64;              // wave-uniform LDS destination (16-byte slots)
+      const uint32_t dstA = __builtin_amdgcn_readfirstlane(st + slot0 * 16);
+      const uint32_t dstB = __builtin_amdgcn_readfirstlane(st + 16384 + slot0 * 16);
+      gb_dma16(A + a_off[i] + k0, dstA);
+      if (B_KROWS) {
+        const int kr = (slot0 + lane) >> 5;
+        const int gk = min(k0 + kr, K - 1);
+        gb_dma16(B + (long)gk * ldb + b_off[i], dstB);
+      } else {
+        gb_dma16(B + b_off[i] + k0, dstB);
+      }
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + G2_BK - 1) / G2_BK;
+  for (int s = 0; s < G2_ST - 1 && s < nk; ++s) issue(s);
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  for (int kt = 0; kt < nk; ++kt) {
+    // the 4 oldest DMAs of this wave (stage kt) must have landed; younger stages stay in flight
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + G2_ST - 1 < nk) issue(kt + G2_ST - 1);      // refills the stage consumed in iteration kt-1
+    const short* Ac = lds + (kt % G2_ST) * G2_STAGE_SHORTS;
+    const short* Bc = Ac + 8192;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v8s a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = wm0 + i * 32 + fr;
+        const int ph = (2 * s + fh) ^ ((x >> 2) & 3);
+        a[i] = *reinterpret_cast<const v8s*>(&Ac[x * 32 + ph * 8]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (B_KROWS) {
+          const int kr = 16 * s + 8 * (tg >> 1) + tq;
+          const int nc = wn0 + j * 32 + 16 * (tg & 1) + 4 * tp;
+          const int ph = (nc >> 3) ^ ((kr & 3) << 2);
+          const int off = kr * 256 + ph * 8 + (nc & 7);
+          v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)&Bc[off]);
+          v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)&Bc[off + 4 * 256]);
+          b[j] = (v8s){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+          const int x = wn0 + j * 32 + fr;
+          const int ph = (2 * s + fh) ^ ((x >> 2) & 3);
+          b[j] = *reinterpret_cast<const v8s*>(&Bc[x * 32 + ph * 8]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[i]),
+                                                               __builtin_bit_cast(v8bf, b[j]), acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn0 + j * 32 + fr;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m >= M) continue;
+        float* o = D + (long)m * ldd + n;
+        float v = acc[i][j][r];
+        if (beta) v += *o;
+        *o = v;
+      }
+    }
+}
+
+// a_kpad: number of readable columns of A (>= K rounded up to 32, zero beyond K)
+extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
+                                int ldd, int M, int N, int K, int beta, void* stream) {
+  MO_CHECK_ARG(A && B && D && M > 0 && N >= 8 && K > 0);
+  MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (!b_krows || (N % 8) == 0));
+  MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
+  const int kpad = (K + 31) / 32 * 32;
+  MO_CHECK_ARG(a_kpad >= kpad && lda >= kpad);
+  MO_CHECK_ARG(b_krows || (K % 32) == 0);          // XROWS B has no zero-padded operand to mask a K tail
+  const int gm = mo_cdiv(M, G2_BM), gn = mo_cdiv(N, G2_BN);
+  dim3 grid(8 * ((gm + 1) / 2) * ((gn + 3) / 4));
+  if (b_krows)
+    hipLaunchKernelGGL(gemm_bf16_256_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
+                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+  else
+    hipLaunchKernelGGL(gemm_bf16_256_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
+                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+  return mo_launch_status();
+}
+
+// fp32 [rows][cols] -> bf16 [rows][ld_out] with zero fill of columns [cols, ld_out)
+__global__ void f32_to_bf16_pad_kernel(const float* __restrict__ x, int rows, int cols, unsigned short* __restrict__ y,
+                                       int ld_out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * ld_out) return;
+  const int r = (int)(i / ld_out), c = (int)(i - (long)r * ld_out);
+  __bf16 t = (__bf16)(c < cols ? x[(long)r * cols + c] : 0.f);
+  y[i] = __builtin_bit_cast(unsigned short, t);
+}
+extern "C" int mo_f32_to_bf16_padded(const float* x, int rows, int cols, void* y, int ld_out, void* stream) {
+  MO_CHECK_ARG(x && y && rows > 0 && cols > 0 && ld_out >= cols);
+  long n = (long)rows * ld_out;
+  hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, cols,
+                     (unsigned short*)y, ld_out);
+  return mo_launch_status();
+}

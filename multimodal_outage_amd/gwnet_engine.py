@@ -54,6 +54,7 @@ class GwnetConfig:
         self.names = names            # parameter order of the autograd Function
         self.grad_out = None          # optional {name: preallocated grad tensor} (flat-buffer trainer)
         self.dense_bf16 = False       # bf16 operands (fp32 accumulate) for the dense adaptive products
+        self.overlap = True           # dense branch on a side stream beside the sparse branch
 
 
 # Optional live kernel timing (bench.py roofline leg): when PROFILE is a list, every dense
@@ -82,14 +83,58 @@ def _bf16(x):
     return y
 
 
+BIG_TILE_MIN_N = 1024   # node count from which the 256x256 LDS-DMA-ring kernel is used
+
+
+def _bf16_padded(x):
+    """(N,N) fp32 -> bf16 [N][Kpad] with zero columns beyond N (Kpad = N rounded up to 32)."""
+    n, k = x.shape
+    kpad = (k + 31) // 32 * 32
+    y = torch.empty((n, kpad), device=x.device, dtype=torch.bfloat16)
+    L.call('mo_f32_to_bf16_padded', L.ptr(x), n, k, L.ptr(y), kpad, L.stream())
+    return y
+
+
+def _use_ring(M, Ncols):
+    """Pick the 256x256 LDS-DMA-ring kernel (one workgroup per CU, ~1.07 PF per full wave of 256 tiles) over
+    the 128x128 kernel (4 workgroups per CU, ~0.7 PF, tolerant of ragged grids) from the tile-grid fill;
+    rates measured with tools/bench_gemm.py on MI355X."""
+    if M < BIG_TILE_MIN_N:
+        return False
+    tiles = ((M + 255) // 256) * ((Ncols + 255) // 256)
+    fill = tiles / (((tiles + 255) // 256) * 256)
+    est128 = 700.0 if Ncols >= 4096 else 190.0 * Ncols / 1024.0
+    return fill * 1070.0 > est128
+
+
 def _adj_prod(A_bf, X_bf, Y, N, J, beta):
-    """Y[N][J] (+)= A_bf[N][N(k)] @ X_bf[N(k)][J]   (bf16 operands, fp32 accumulate)."""
-    _dense('mo_gemm_bf16', N, J, L.ptr(A_bf), N, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta, L.stream())
+    """Y[N][J] (+)= A_bf[N][N(k)] @ X_bf[N(k)][J]   (bf16 operands, fp32 accumulate); A_bf is [N][Kpad]."""
+    kpad = A_bf.shape[1]
+    if _use_ring(N, J):
+        _dense('mo_gemm_bf16_256', N, J, L.ptr(A_bf), kpad, kpad, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta,
+               L.stream())
+    else:
+        _dense('mo_gemm_bf16', N, J, L.ptr(A_bf), kpad, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta, L.stream())
 
 
 def _adj_grad_bf(X_bf, dY_bf, dA, N, J, beta):
     """dA[N][N] (+)= X_bf[N][J] @ dY_bf[N][J]^T."""
-    _dense('mo_gemm_bf16', N, J, L.ptr(X_bf), J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta, L.stream())
+    if N >= BIG_TILE_MIN_N:
+        _dense('mo_gemm_bf16_256', N, J, L.ptr(X_bf), J, J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta,
+               L.stream())
+    else:
+        _dense('mo_gemm_bf16', N, J, L.ptr(X_bf), J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta, L.stream())
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """One side HIP stream per device for the dense adaptive-adjacency branch."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def _spmm(csr, n, X, Y, J, beta):
@@ -129,7 +174,7 @@ class GwnetFunction(torch.autograd.Function):
         use_bf = bool(cfg.dense_bf16 and adp is not None and N % 8 == 0)
         adp_bf = adpT_bf = None
         if use_bf:
-            adp_bf, adpT_bf = _bf16(adp), _bf16(adpT)
+            adp_bf, adpT_bf = _bf16_padded(adp), _bf16_padded(adpT)
         skip = _e(G * Tf, cfg.Cs, dev)
         drop_p = cfg.dropout if training else 0.0
         thresh = int(min(max(drop_p, 0.0), 0.999999) * 4294967296.0) if drop_p > 0 else 0
@@ -157,25 +202,36 @@ class GwnetFunction(torch.autograd.Function):
             srcs = [g]
             bf_saved = None
             if cfg.gcn:
+                # the dense (adaptive, MFMA-bound) branch runs on a side HIP stream beside the sparse
+                # (static CSR, HBM-bound) branch; both only read g and are joined in front of the mlp
+                side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap) else None
+                dense_out = []
+                if cfg.adaptive:
+                    x1 = _e(P, 32, dev)
+                    x2 = _e(P, 32, dev)
+                    main = torch.cuda.current_stream()
+                    if side is not None:
+                        side.wait_stream(main)
+                    with torch.cuda.stream(side if side is not None else main):
+                        if use_bf:
+                            g_bf = _bf16(g)
+                            _adj_prod(adpT_bf, g_bf, x1, N, J, 0)
+                            x1_bf = _bf16(x1)
+                            _adj_prod(adpT_bf, x1_bf, x2, N, J, 0)
+                            bf_saved = (g_bf, x1_bf)
+                        else:
+                            _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, L.stream())
+                            _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, L.stream())
+                    dense_out = [x1, x2]
                 for s in statics:
                     x1 = _e(P, 32, dev)
                     x2 = _e(P, 32, dev)
                     _spmm(s.fwd, N, g, x1, J, 0)
                     _spmm(s.fwd, N, x1, x2, J, 0)
                     srcs += [x1, x2]
-                if cfg.adaptive:
-                    x1 = _e(P, 32, dev)
-                    x2 = _e(P, 32, dev)
-                    if use_bf:
-                        g_bf = _bf16(g)
-                        _adj_prod(adpT_bf, g_bf, x1, N, J, 0)
-                        x1_bf = _bf16(x1)
-                        _adj_prod(adpT_bf, x1_bf, x2, N, J, 0)
-                        bf_saved = (g_bf, x1_bf)
-                    else:
-                        _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, st)
-                        _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, st)
-                    srcs += [x1, x2]
+                srcs += dense_out
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
                 W, bb = p[f'gconv.{i}.mlp.mlp.weight'], p[f'gconv.{i}.mlp.mlp.bias']
                 lt, ls, seed = thresh, dscale, (base_seed + 7919 * i) & 0xFFFFFFFF
             else:
@@ -300,30 +356,43 @@ class GwnetFunction(torch.autograd.Function):
                 dg = dsrcs[0]
                 k = 1
                 if cfg.gcn:
+                    ka = 1 + 2 * len(statics)
+                    side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap) else None
+                    if cfg.adaptive:
+                        # dense branch, part 1 (does not touch dg): dx1 += adp.dx2 ; dA += x1.dx2^T ; dA += g.dx1^T
+                        x1 = srcs[ka]
+                        dx1, dx2 = dsrcs[ka], dsrcs[ka + 1]
+                        main = torch.cuda.current_stream()
+                        if side is not None:
+                            side.wait_stream(main)
+                        with torch.cuda.stream(side if side is not None else main):
+                            if ly['bf'] is not None:
+                                g_bf, x1_bf = ly['bf']
+                                dx2_bf = _bf16(dx2)
+                                _adj_prod(ctx.adp_bf, dx2_bf, dx1, N, J, 1)
+                                _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
+                                dx1_bf = _bf16(dx1)
+                                _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
+                            else:
+                                sst = L.stream()
+                                _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, sst)
+                                _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
+                                       1 if dAdp_started else 0, sst)
+                                _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, sst)
+                            dAdp_started = True
                     for s in statics:
-                        dx1, dx2 = dsrcs[k], dsrcs[k + 1]
-                        _spmm(s.bwd, N, dx2, dx1, J, 1)
-                        _spmm(s.bwd, N, dx1, dg, J, 1)
+                        dx1s, dx2s = dsrcs[k], dsrcs[k + 1]
+                        _spmm(s.bwd, N, dx2s, dx1s, J, 1)
+                        _spmm(s.bwd, N, dx1s, dg, J, 1)
                         k += 2
                     if cfg.adaptive:
-                        x1 = srcs[k]
-                        dx1, dx2 = dsrcs[k], dsrcs[k + 1]
+                        if side is not None:
+                            torch.cuda.current_stream().wait_stream(side)
+                        # dense branch, part 2: dg += adp.dx1 (after the sparse accumulations into dg)
                         if ly['bf'] is not None:
-                            g_bf, x1_bf = ly['bf']
-                            dx2_bf = _bf16(dx2)
-                            _adj_prod(ctx.adp_bf, dx2_bf, dx1, N, J, 1)
-                            _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
-                            dAdp_started = True
-                            dx1_bf = _bf16(dx1)
                             _adj_prod(ctx.adp_bf, dx1_bf, dg, N, J, 1)
-                            _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
                         else:
-                            _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, st)
-                            _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
-                                   1 if dAdp_started else 0, st)
-                            dAdp_started = True
                             _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx1), L.ptr(dg), J, 1, st)
-                            _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, st)
                 beta = 1
             else:
                 dg = torch.zeros((P, 32), device=dev, dtype=torch.float32)

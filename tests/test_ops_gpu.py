@@ -437,3 +437,26 @@ def test_gemm_bf16(L, M, N, K, krows):
         L.call('mo_gemm_bf16', L.ptr(Ab), K, L.ptr(Bb), N if krows else K, 1 if krows else 0, L.ptr(D), N, M, N, K,
                beta, L.stream())
         close(D, ref + (D0 if beta else 0), 2e-5, f'gemm_bf16 beta={beta}')
+
+
+@pytest.mark.parametrize('M,N,K,krows', [(256, 256, 32, True), (3000, 1536, 3000, True), (300, 264, 296, True),
+                                         (517, 96, 1000, True), (3000, 3000, 1024, False), (200, 136, 64, False)])
+def test_gemm_bf16_256_dma_ring(L, M, N, K, krows):
+    """256x256 tile / 4-stage LDS-DMA ring variant: same answer as an fp32 matmul of the bf16-rounded operands
+    (asymmetric random data; edge tiles in M, N and a K tail masked by the zero-padded A columns)."""
+    A = rand(93, (M, K))
+    B = rand(94, (K, N)) if krows else rand(94, (N, K))
+    kpad = (K + 31) // 32 * 32
+    Ab = torch.full((M, kpad), float('nan'), device='cuda', dtype=torch.bfloat16)
+    L.call('mo_f32_to_bf16_padded', L.ptr(dev(A)), M, K, L.ptr(Ab), kpad, L.stream())
+    assert torch.equal(Ab[:, :K].cpu(), A.to(torch.bfloat16)) and float(Ab[:, K:].float().abs().sum()) == 0.0
+    Bb = torch.empty(B.shape, device='cuda', dtype=torch.bfloat16)
+    L.call('mo_f32_to_bf16', L.ptr(dev(B)), L.ptr(Bb), B.numel(), L.stream())
+    Ar, Br = A.to(torch.bfloat16).float(), B.to(torch.bfloat16).float()
+    ref = Ar @ (Br if krows else Br.t())
+    D0 = rand(95, (M, N))
+    for beta in (0, 1):
+        D = dev(D0.clone())
+        L.call('mo_gemm_bf16_256', L.ptr(Ab), kpad, kpad, L.ptr(Bb), N if krows else K, 1 if krows else 0, L.ptr(D), N,
+               M, N, K, beta, L.stream())
+        close(D, ref + (D0 if beta else 0), 2e-5, f'gemm_bf16_256 beta={beta}')
