@@ -63,7 +63,7 @@ int mo_adp_bwd(const float* E1, const float* E2, const float* adp, float* dA, in
 int mo_tcn_pack_weights(const float* Wf, const float* Wg, int K, float* Wp, void* stream);
 int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
-               void* stream);
+               void* g_bf16 /* optional bf16 copy of g_out, may be NULL */, void* stream);
 /* backward: recomputes the pre-activations; dpre (ws, G*Tout*64 floats) ; du[G*Tin][32] = conv^T(dpre)
  * (+ dres[(g,t-(Tin-Tout))] when dres != null: the residual path of graph_wavenet.py:247);
  * dWf,dWg (32,32,1,K), dbf,dbg (32). ws2: mo_wgrad_ws_floats(64, 32*K, G*Tout) floats. */
@@ -88,13 +88,13 @@ int mo_adj_grad(const float* X, const float* dY, int N, long J, float* dA, int b
  * activation matrix as stored; fetched with ds_read_b64_tr_b16) or [N][K] (b_krows=0).  lda, ldb, K
  * (and N when b_krows) must be multiples of 8.  mo_f32_to_bf16: round-to-nearest-even, n % 8 == 0. */
 int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
-                 int N, int K, int beta, void* stream);
+                 int N, int K, int beta, void* D_bf16 /* optional bf16 copy of D, may be NULL */, void* stream);
 int mo_f32_to_bf16(const float* x, void* y, long n, void* stream);
 /* 256x256x32-tile variant with a 4-stage LDS-DMA ring (three k-tiles in flight): same contract, plus: A must be
  * readable and zero in columns [K, a_kpad) with a_kpad >= K rounded up to 32 (mo_f32_to_bf16_padded makes such
  * a copy); K % 32 == 0 when b_krows == 0. */
 int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
-                     int ldd, int M, int N, int K, int beta, void* stream);
+                     int ldd, int M, int N, int K, int beta, void* D_bf16, void* stream);
 int mo_f32_to_bf16_padded(const float* x, int rows, int cols, void* y, int ld_out, void* stream);
 
 /* ---- gcn mlp + dropout + residual + BatchNorm statistics (graph_wavenet.py:95-97,247,250) -------
@@ -119,7 +119,8 @@ int mo_bn_bwd(const float* dy, const float* h, long P, const float* gamma, const
  * ws: mo_wgrad_ws_floats(32, ns*32, P) floats. */
 int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrcs, int ns,
                    const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
-                   float* dW, float* db, float* ws, void* stream);
+                   float* dW, float* db, float* ws, void* dlast_bf16 /* optional bf16 copy of dsrcs[ns-1] */,
+                   void* stream);
 
 /* ---- loss + metrics (lit.py:33-38): sums[0..3] = {sum d^2, sum |d|, sum |d|/max(|y|,1.17e-6), n};
  *      grad (optional) = 2*d/n.  ws: mo_metrics_ws_floats(n). --------------------------------------- */

@@ -32,7 +32,7 @@ __device__ __forceinline__ uint4 gb_load16(const short* base, long row, int ld, 
 template <bool B_KROWS>
 __global__ void __launch_bounds__(256)
 gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ D,
-                 int ldd, int M, int N, int K, int beta) {
+                 int ldd, int M, int N, int K, int beta, unsigned short* __restrict__ Dbf) {
   __shared__ __attribute__((aligned(16))) short As[2][GB_BM * GB_LDA];
   __shared__ __attribute__((aligned(16))) short Bs[2][B_KROWS ? GB_BK * GB_LDB : GB_BN * GB_LDA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,12 +151,13 @@ gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__
         float v = acc[i][j][r];
         if (beta) v += *o;
         *o = v;
+        if (Dbf) { __bf16 t = (__bf16)v; Dbf[(long)m * ldd + n] = __builtin_bit_cast(unsigned short, t); }
       }
     }
 }
 
 extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
-                            int N, int K, int beta, void* stream) {
+                            int N, int K, int beta, void* D_bf16, void* stream) {
   MO_CHECK_ARG(A && B && D && M > 0 && N > 0 && K > 0);
   // 16-byte chunk loads: leading dimensions and the contiguous extents must be multiples of 8 elements
   MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (K % 8) == 0 && (!b_krows || (N % 8) == 0));
@@ -165,10 +166,10 @@ extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int 
   dim3 grid(8 * ((gm + 1) / 2) * ((gn + 3) / 4));
   if (b_krows)
     hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
   else
     hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
   return mo_launch_status();
 }
 
@@ -229,7 +230,7 @@ __device__ __forceinline__ void gb_dma16(const void* gsrc, uint32_t lds_byte_off
 template <bool B_KROWS>
 __global__ void __launch_bounds__(512)
 gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ D,
-                     int ldd, int M, int N, int K, int beta) {
+                     int ldd, int M, int N, int K, int beta, unsigned short* __restrict__ Dbf) {
   __shared__ __attribute__((aligned(16))) short lds[G2_ST * G2_STAGE_SHORTS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,13 +360,14 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
         float v = acc[i][j][r];
         if (beta) v += *o;
         *o = v;
+        if (Dbf) { __bf16 t = (__bf16)v; Dbf[(long)m * ldd + n] = __builtin_bit_cast(unsigned short, t); }
       }
     }
 }
 
 // a_kpad: number of readable columns of A (>= K rounded up to 32, zero beyond K)
 extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
-                                int ldd, int M, int N, int K, int beta, void* stream) {
+                                int ldd, int M, int N, int K, int beta, void* D_bf16, void* stream) {
   MO_CHECK_ARG(A && B && D && M > 0 && N >= 8 && K > 0);
   MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (!b_krows || (N % 8) == 0));
   MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
@@ -376,10 +378,10 @@ extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* 
   dim3 grid(8 * ((gm + 1) / 2) * ((gn + 3) / 4));
   if (b_krows)
     hipLaunchKernelGGL(gemm_bf16_256_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
   else
     hipLaunchKernelGGL(gemm_bf16_256_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
   return mo_launch_status();
 }
 

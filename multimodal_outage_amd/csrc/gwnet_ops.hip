@@ -33,7 +33,7 @@ static void epi_init(MoEpi& e, float* out, int ldo) {
   e.add = nullptr; e.ldadd = 0; e.aTo = 0; e.aTi = 0; e.aoff = 0; e.ascale = nullptr; e.ashift = nullptr;
   e.aux = nullptr; e.ldaux = 0;
   e.drop_seed = 0; e.drop_thresh = 0; e.drop_scale = 1.f;
-  e.partial = nullptr; e.slab_stride = 0; e.kchunk = 0; e.colsum = nullptr;
+  e.partial = nullptr; e.slab_stride = 0; e.kchunk = 0; e.colsum = nullptr; e.out_bf = nullptr; e.bf_seg = 0;
 }
 
 // The branch-free vector loader applies when every segment is 16-byte loadable, segments are 32/64 wide,
@@ -464,14 +464,14 @@ static void tcn_operands(const float* h_prev, const float* scale, const float* s
 
 extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                           const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
-                          void* stream) {
+                          void* g_bf16, void* stream) {
   const int Tout = Tin - dil * (K - 1);
   MO_CHECK_ARG(h_prev && Wp && bf && bg && g_out && K >= 1 && K <= MO_MAX_SEG && G > 0 && Tout > 0);
   MO_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   MO_CHECK_ARG(G * Tin < (1L << 31));
   MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
   MoEpi E; epi_init(E, g_out, 32);
-  E.bias = bf; E.bias2 = bg;
+  E.bias = bf; E.bias2 = bg; E.out_bf = (unsigned short*)g_bf16;
   return launch<128, 64, 32, 4, 1, MO_XROWS, MO_XROWS, MO_EPI_GATE>(A, Bo, E, G * Tout, 64, 1, ST(stream));
 }
 
@@ -795,7 +795,7 @@ __global__ void mlp_bias_grad_kernel(const float* __restrict__ dh, long P, uint3
 
 extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrcs, int ns,
                               const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
-                              float* dW, float* db, float* ws, void* stream) {
+                              float* dW, float* db, float* ws, void* dlast_bf16, void* stream) {
   MO_CHECK_ARG(dh && srcs && dsrcs && W && dW && db && ws && ns >= 1 && ns <= MO_MAX_SEG && P > 0 && P < (1L << 31));
   hipStream_t st = ST(stream);
   // data: dsrcs[s][p][c] = sum_co dm[p][co] W[co][s*32+c]
@@ -804,6 +804,7 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
   MoOperand Bo = op_simple(W, 32 * ns, 32, 32 * ns);      // KROWS rows = k = co, cols = n
   MoEpi E; epi_init(E, dsrcs[0], 32);
   E.nout = ns; E.osegw = 32;
+  E.out_bf = (unsigned short*)dlast_bf16; E.bf_seg = ns - 1;    // bf16 copy of the last source's gradient
   for (int s = 0; s < ns; ++s) { MO_CHECK_ARG(dsrcs[s] && srcs[s]); E.out[s] = dsrcs[s]; }
   int rc;
   if (ns == 1)

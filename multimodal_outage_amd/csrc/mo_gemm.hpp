@@ -83,6 +83,8 @@ struct MoEpi {
   long slab_stride;        // split-K: slab z goes to out + z*slab_stride
   int kchunk;              // split-K chunk (multiple of BK); 0: whole K
   float* colsum;           // FAST, A in KROWS mode: per-slice column sums of A, [gridDim.z][M] (bias gradient)
+  unsigned short* out_bf;  // optional bf16 copy: GATE: of g; STORE: of output segment bf_seg (same row stride)
+  int bf_seg;
 };
 
 // Loads through descriptor pointers (which travel through LDS and lose their address space) must be
@@ -501,6 +503,10 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
           float* o = obase + orow * E.ldo + on;
           if (E.beta) v += *o;
           *o = v;
+          if (E.out_bf && os == E.bf_seg) {
+            __bf16 tb = (__bf16)v;
+            E.out_bf[orow * E.ldo + on] = __builtin_bit_cast(unsigned short, tb);
+          }
         }
       }
     }
@@ -518,6 +524,7 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
         const float g = mo_sigmoid(acc[i][TN - 1][r] + bg);
         if (EPI == MO_EPI_GATE) {
           E.out[0][(long)m * E.ldo + c] = f * g;
+          if (E.out_bf) { __bf16 tb = (__bf16)(f * g); E.out_bf[(long)m * E.ldo + c] = __builtin_bit_cast(unsigned short, tb); }
         } else {
           const float dg = E.aux[(long)m * E.ldaux + c];
           E.out[0][(long)m * E.ldo + c] = dg * g * (1.f - f * f);

@@ -28,6 +28,7 @@ static void uepi(MoEpi& e, float* out, long ldo) {
   e.mask = nullptr; e.ldmask = 0; e.add = nullptr; e.ldadd = 0; e.aTo = 0; e.aTi = 0; e.aoff = 0;
   e.ascale = nullptr; e.ashift = nullptr; e.aux = nullptr; e.ldaux = 0;
   e.drop_seed = 0; e.drop_thresh = 0; e.drop_scale = 1.f; e.partial = nullptr; e.slab_stride = 0; e.kchunk = 0;
+  e.colsum = nullptr; e.out_bf = nullptr; e.bf_seg = 0;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int AM, int BMODE, int EPI, int ASRC, int BSRC>

@@ -107,23 +107,26 @@ def _use_ring(M, Ncols):
     return fill * 1070.0 > est128
 
 
-def _adj_prod(A_bf, X_bf, Y, N, J, beta):
-    """Y[N][J] (+)= A_bf[N][N(k)] @ X_bf[N(k)][J]   (bf16 operands, fp32 accumulate); A_bf is [N][Kpad]."""
+def _adj_prod(A_bf, X_bf, Y, N, J, beta, Y_bf=None):
+    """Y[N][J] (+)= A_bf[N][N(k)] @ X_bf[N(k)][J]   (bf16 operands, fp32 accumulate); A_bf is [N][Kpad].
+    Y_bf: optional bf16 copy of the result written by the same epilogue."""
     kpad = A_bf.shape[1]
     if _use_ring(N, J):
         _dense('mo_gemm_bf16_256', N, J, L.ptr(A_bf), kpad, kpad, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta,
-               L.stream())
+               L.ptr(Y_bf), L.stream())
     else:
-        _dense('mo_gemm_bf16', N, J, L.ptr(A_bf), kpad, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta, L.stream())
+        _dense('mo_gemm_bf16', N, J, L.ptr(A_bf), kpad, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta, L.ptr(Y_bf),
+               L.stream())
 
 
 def _adj_grad_bf(X_bf, dY_bf, dA, N, J, beta):
     """dA[N][N] (+)= X_bf[N][J] @ dY_bf[N][J]^T."""
     if N >= BIG_TILE_MIN_N:
-        _dense('mo_gemm_bf16_256', N, J, L.ptr(X_bf), J, J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta,
+        _dense('mo_gemm_bf16_256', N, J, L.ptr(X_bf), J, J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta, None,
                L.stream())
     else:
-        _dense('mo_gemm_bf16', N, J, L.ptr(X_bf), J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta, L.stream())
+        _dense('mo_gemm_bf16', N, J, L.ptr(X_bf), J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta, None,
+               L.stream())
 
 
 _SIDE = {}
@@ -193,9 +196,10 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_tcn_pack_weights', L.ptr(p[f'filter_convs.{i}.weight']),
                    L.ptr(p[f'gate_convs.{i}.weight']), K, L.ptr(Wp), st)
             g = _e(P, 32, dev)
+            g_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16) if use_bf else None
             L.call('mo_tcn_fwd', L.ptr(h), L.ptr(scale), L.ptr(shift), L.ptr(Wp),
                    L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, d, G, Tin,
-                   L.ptr(g), st)
+                   L.ptr(g), L.ptr(g_bf), st)
             L.call('mo_conv1x1_fwd', L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
                    L.ptr(p[f'skip_convs.{i}.weight']), L.ptr(p[f'skip_convs.{i}.bias']), cfg.Cs,
                    L.ptr(skip), G * Tf, 0, 1 if i > 0 else 0, st)
@@ -214,9 +218,8 @@ class GwnetFunction(torch.autograd.Function):
                         side.wait_stream(main)
                     with torch.cuda.stream(side if side is not None else main):
                         if use_bf:
-                            g_bf = _bf16(g)
-                            _adj_prod(adpT_bf, g_bf, x1, N, J, 0)
-                            x1_bf = _bf16(x1)
+                            x1_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
+                            _adj_prod(adpT_bf, g_bf, x1, N, J, 0, x1_bf)
                             _adj_prod(adpT_bf, x1_bf, x2, N, J, 0)
                             bf_saved = (g_bf, x1_bf)
                         else:
@@ -350,8 +353,10 @@ class GwnetFunction(torch.autograd.Function):
                     kW, kb = f'residual_convs.{i}.weight', f'residual_convs.{i}.bias'
                 gW = gbuf(kW, W); gbm = gbuf(kb, shape=(32,))
                 wsm = ws_for(32, 32 * ns, P)
+                dx2_bf = (torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
+                          if (ly['bf'] is not None and cfg.gcn and cfg.adaptive) else None)
                 L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
-                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), L.ptr(wsm), st)
+                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), L.ptr(wsm), L.ptr(dx2_bf), st)
                 grads[kW], grads[kb] = gW, gbm
                 dg = dsrcs[0]
                 k = 1
@@ -368,10 +373,9 @@ class GwnetFunction(torch.autograd.Function):
                         with torch.cuda.stream(side if side is not None else main):
                             if ly['bf'] is not None:
                                 g_bf, x1_bf = ly['bf']
-                                dx2_bf = _bf16(dx2)
-                                _adj_prod(ctx.adp_bf, dx2_bf, dx1, N, J, 1)
+                                dx1_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
+                                _adj_prod(ctx.adp_bf, dx2_bf, dx1, N, J, 1, dx1_bf)
                                 _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
-                                dx1_bf = _bf16(dx1)
                                 _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
                             else:
                                 sst = L.stream()

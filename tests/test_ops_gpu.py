@@ -197,10 +197,12 @@ def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine):
     L.call('mo_tcn_pack_weights', L.ptr(dev(Wf.detach())), L.ptr(dev(Wg.detach())), K, L.ptr(Wp), L.stream())
     hp = dev(nbtc(hprev.detach()))
     g = torch.empty(G * Tout, 32, device='cuda')
+    g_bf = torch.empty(G * Tout, 32, device='cuda', dtype=torch.bfloat16)
     scd, shd = (dev(sc), dev(sh)) if affine else (None, None)
     L.call('mo_tcn_fwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
-           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(g), L.stream())
+           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(g), L.ptr(g_bf), L.stream())
     close(g, nbtc(g_ref), what='g')
+    assert torch.equal(g_bf.cpu(), g.cpu().to(torch.bfloat16))          # fused bf16 copy == RNE of the fp32 result
 
     dg = rand(27, tuple(g_ref.shape))
     dres = rand(28, tuple(g_ref.shape))        # residual-path gradient, cropped add (graph_wavenet.py:247)
@@ -359,8 +361,10 @@ def test_gcn_mlp_bn(L, B, N, Tin, Tout, ns, drop, affine):
     dsrcs = [torch.empty(P, 32, device='cuda') for _ in range(ns)]
     dW = torch.empty(32, 32 * ns, device='cuda'); db = torch.empty(32, device='cuda')
     wsm = torch.empty(lib.mo_wgrad_ws_floats(32, 32 * ns, P), device='cuda')
+    dlast_bf = torch.empty(P, 32, device='cuda', dtype=torch.bfloat16)
     L.call('mo_gcn_mlp_bwd', L.ptr(dev(dhh)), L.ptr_array(sd), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P,
-           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), L.stream())
+           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), L.ptr(dlast_bf), L.stream())
+    assert torch.equal(dlast_bf.cpu(), dsrcs[ns - 1].cpu().to(torch.bfloat16))
     for s in range(ns):
         close(dsrcs[s], dcat[:, 32 * s:32 * (s + 1)], what=f'dsrc{s}')
     close(dW, dm.t() @ cat, what='dWm')
@@ -434,8 +438,10 @@ def test_gemm_bf16(L, M, N, K, krows):
     D0 = rand(92, (M, N))
     for beta in (0, 1):
         D = dev(D0.clone())
+        Dbf = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
         L.call('mo_gemm_bf16', L.ptr(Ab), K, L.ptr(Bb), N if krows else K, 1 if krows else 0, L.ptr(D), N, M, N, K,
-               beta, L.stream())
+               beta, L.ptr(Dbf), L.stream())
+        assert torch.equal(Dbf.cpu(), D.cpu().to(torch.bfloat16))
         close(D, ref + (D0 if beta else 0), 2e-5, f'gemm_bf16 beta={beta}')
 
 
@@ -457,6 +463,9 @@ def test_gemm_bf16_256_dma_ring(L, M, N, K, krows):
     D0 = rand(95, (M, N))
     for beta in (0, 1):
         D = dev(D0.clone())
+        Dbf = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
         L.call('mo_gemm_bf16_256', L.ptr(Ab), kpad, kpad, L.ptr(Bb), N if krows else K, 1 if krows else 0, L.ptr(D), N,
-               M, N, K, beta, L.stream())
+               M, N, K, beta, L.ptr(Dbf) if beta else None, L.stream())
+        if beta:
+            assert torch.equal(Dbf.cpu(), D.cpu().to(torch.bfloat16))
         close(D, ref + (D0 if beta else 0), 2e-5, f'gemm_bf16_256 beta={beta}')

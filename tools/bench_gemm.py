@@ -21,9 +21,9 @@ for J in (1024, 3072, 6144, 12288, 24576):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 10
     fl = 2.0 * N * N * J
-    t128 = run('mo_gemm_bf16', L.ptr(A), kpad, L.ptr(X), J, 1, L.ptr(Y), J, N, J, N, 0, st)
-    t256 = run('mo_gemm_bf16_256', L.ptr(A), kpad, kpad, L.ptr(X), J, 1, L.ptr(Y), J, N, J, N, 0, st)
-    g128 = run('mo_gemm_bf16', L.ptr(X), J, L.ptr(X), J, 0, L.ptr(dA), N, N, N, J, 0, st)
-    g256 = run('mo_gemm_bf16_256', L.ptr(X), J, J, L.ptr(X), J, 0, L.ptr(dA), N, N, N, J, 0, st)
+    t128 = run('mo_gemm_bf16', L.ptr(A), kpad, L.ptr(X), J, 1, L.ptr(Y), J, N, J, N, 0, None, st)
+    t256 = run('mo_gemm_bf16_256', L.ptr(A), kpad, kpad, L.ptr(X), J, 1, L.ptr(Y), J, N, J, N, 0, None, st)
+    g128 = run('mo_gemm_bf16', L.ptr(X), J, L.ptr(X), J, 0, L.ptr(dA), N, N, N, J, 0, None, st)
+    g256 = run('mo_gemm_bf16_256', L.ptr(X), J, J, L.ptr(X), J, 0, L.ptr(dA), N, N, N, J, 0, None, st)
     print(f'J={J:6d} prod: 128-tile {fl/t128/1e9:7.1f} TF ({t128*1e3:.0f} us)  256-ring {fl/t256/1e9:7.1f} TF ({t256*1e3:.0f} us) | '
           f'grad: 128 {fl/g128/1e9:7.1f} TF  256 {fl/g256/1e9:7.1f} TF')
