@@ -172,6 +172,15 @@ def main():
     dt = time.perf_counter() - t0
     prof, engine.PROFILE = engine.PROFILE, None
     loss = float(sums[0].item()) / n_out
+    # the same kernels without the side-stream overlap (2 extra untimed-for-throughput steps): their
+    # un-contended duration, reported beside the timed-region figure
+    engine.SERIAL = True
+    engine.PROFILE = []
+    for _ in range(2):
+        step()
+    sync()
+    prof_serial, engine.PROFILE = engine.PROFILE, None
+    engine.SERIAL = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,6 +192,8 @@ def main():
     gemm_flops = sum(f for (_, f, _, _) in prof)
     n_launch = max(len(prof), 1)
     ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    ser_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1) in prof_serial)
+    ser_ach = sum(f for (_, f, _, _) in prof_serial) / (ser_ms * 1e-3) / 1e12 if ser_ms > 0 else 0.0
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
     kname = ("gemm_bf16_256_kernel<256x256x32, 4-stage LDS-DMA ring, mfma_f32_32x32x16_bf16>" if args.dtype == 'bf16'
              else "mo_gemm_kernel<128,128,16, mfma_f32_32x32x2_f32>")
@@ -192,6 +203,11 @@ def main():
                 "frac": round(ach / peak, 4),
                 "launches": len(prof), "avg_launch_ms": round(gemm_ms / n_launch, 4),
                 "avg_launch_gflop": round(gemm_flops / n_launch / 1e9, 3),
+                "note": "timed region: the product runs on a side stream beside the HBM-bound sparse branch and the "
+                        "weight-gradient lane, so its launches are stretched by contention; *_serial = same launches "
+                        "with the overlap disabled (2 extra steps after the timed region)",
+                "achieved_serial": round(ser_ach, 3), "frac_serial": round(ser_ach / peak, 4),
+                "avg_launch_ms_serial": round(ser_ms / max(len(prof_serial), 1), 4),
                 "traffic": pmc_traffic(args.dtype, B)}
     # secondary: the whole step (TCN gate, SpMM, mlp+BN, skip, head, their backward AND the dense products, which
     # overlap the sparse branch on a side stream) priced against the HBM roofline with the compulsory-traffic

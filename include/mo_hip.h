@@ -70,7 +70,8 @@ int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, cons
 int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                const float* bf, const float* bg, int K, int dil, long G, int Tin, const float* dg,
                const float* dres, float* du, float* dWf, float* dWg, float* dbf, float* dbg,
-               float* dpre_ws, float* ws2, void* stream);
+               float* dpre_ws, float* ws2, int parts /* 1: dpre + data gradient, 2: weight/bias gradients
+               (needs dpre of part 1), 3: both */, void* stream);
 
 /* ---- diffusion graph convolution, node-axis products (nconv, graph_wavenet.py:64-66) -----------
  * Y[w][:] (+)= sum_e vals[e] * X[colidx[e]][:],  e in [rowptr[w], rowptr[w+1]);  rows of J floats.
@@ -120,7 +121,7 @@ int mo_bn_bwd(const float* dy, const float* h, long P, const float* gamma, const
 int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrcs, int ns,
                    const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
                    float* dW, float* db, float* ws, void* dlast_bf16 /* optional bf16 copy of dsrcs[ns-1] */,
-                   void* stream);
+                   int parts /* 1: data gradients, 2: weight/bias gradients, 3: both */, void* stream);
 
 /* ---- loss + metrics (lit.py:33-38): sums[0..3] = {sum d^2, sum |d|, sum |d|/max(|y|,1.17e-6), n};
  *      grad (optional) = 2*d/n.  ws: mo_metrics_ws_floats(n). --------------------------------------- */

@@ -478,20 +478,23 @@ extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* 
 extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                           const float* bf, const float* bg, int K, int dil, long G, int Tin, const float* dg,
                           const float* dres, float* du, float* dWf, float* dWg, float* dbf, float* dbg,
-                          float* dpre_ws, float* ws2, void* stream) {
+                          float* dpre_ws, float* ws2, int parts, void* stream) {
   const int Tout = Tin - dil * (K - 1);
   MO_CHECK_ARG(h_prev && Wp && bf && bg && dg && dWf && dWg && dbf && dbg && dpre_ws && ws2);
   MO_CHECK_ARG(K >= 1 && K <= MO_MAX_SEG && G > 0 && Tout > 0 && G * Tin < (1L << 31));
   hipStream_t st = ST(stream);
   const long Pout = G * Tout, Pin = G * Tin;
+  int rc = MO_OK;
   // 1) recompute pre-activations, dpre[p][0:32] = d/d(filter pre-act), [32:64] = d/d(gate pre-act)
-  MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
-  MoEpi E; epi_init(E, dpre_ws, 64);
-  E.bias = bf; E.bias2 = bg; E.aux = dg; E.ldaux = 32;
-  int rc = launch<128, 64, 32, 4, 1, MO_XROWS, MO_XROWS, MO_EPI_GATE_BWD>(A, Bo, E, Pout, 64, 1, st);
-  if (rc) return rc;
+  if (parts & 1) {
+    MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
+    MoEpi E; epi_init(E, dpre_ws, 64);
+    E.bias = bf; E.bias2 = bg; E.aux = dg; E.ldaux = 32;
+    rc = launch<128, 64, 32, 4, 1, MO_XROWS, MO_XROWS, MO_EPI_GATE_BWD>(A, Bo, E, Pout, 64, 1, st);
+    if (rc) return rc;
+  }
   // 2) data gradient: du[(g,t)][ci] = sum_tau sum_co' dpre[(g,t-tau*d)][co'] Wp[tau][co'][ci]  (+ residual)
-  if (du) {
+  if ((parts & 1) && du) {
     MoOperand A2; op_init(A2);
     A2.nseg = K; A2.segw = 64; A2.rows = (int)Pin; A2.cols = 64 * K;
     for (int t = 0; t < K; ++t) {
@@ -505,7 +508,7 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
     if (rc) return rc;
   }
   // 3) weight gradients: slab[co'][tau*32+ci] = sum_p dpre[p][co'] * u[(g,t+tau*d)][ci]
-  {
+  if (parts & 2) {
     MoOperand A3 = op_simple(dpre_ws, 64, Pout, 64);   // KROWS rows = p, cols = co'
     MoOperand B3; op_init(B3);
     B3.nseg = K; B3.segw = 32; B3.rows = (int)Pout; B3.cols = 32 * K;
@@ -795,8 +798,9 @@ __global__ void mlp_bias_grad_kernel(const float* __restrict__ dh, long P, uint3
 
 extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrcs, int ns,
                               const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
-                              float* dW, float* db, float* ws, void* dlast_bf16, void* stream) {
-  MO_CHECK_ARG(dh && srcs && dsrcs && W && dW && db && ws && ns >= 1 && ns <= MO_MAX_SEG && P > 0 && P < (1L << 31));
+                              float* dW, float* db, float* ws, void* dlast_bf16, int parts, void* stream) {
+  MO_CHECK_ARG(dh && srcs && dsrcs && W && dW && db && ns >= 1 && ns <= MO_MAX_SEG && P > 0 && P < (1L << 31));
+  MO_CHECK_ARG(ws || !(parts & 2));
   hipStream_t st = ST(stream);
   // data: dsrcs[s][p][c] = sum_co dm[p][co] W[co][s*32+c]
   MoOperand A = op_simple(dh, 32, P, 32);                 // XROWS rows = p, cols = k = co
@@ -806,12 +810,15 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
   E.nout = ns; E.osegw = 32;
   E.out_bf = (unsigned short*)dlast_bf16; E.bf_seg = ns - 1;    // bf16 copy of the last source's gradient
   for (int s = 0; s < ns; ++s) { MO_CHECK_ARG(dsrcs[s] && srcs[s]); E.out[s] = dsrcs[s]; }
-  int rc;
-  if (ns == 1)
-    rc = launch<128, 32, 32, 4, 1, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, 32, 1, st);
-  else
-    rc = launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, 32 * ns, 1, st);
-  if (rc) return rc;
+  int rc = MO_OK;
+  if (parts & 1) {
+    if (ns == 1)
+      rc = launch<128, 32, 32, 4, 1, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, 32, 1, st);
+    else
+      rc = launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, 32 * ns, 1, st);
+    if (rc) return rc;
+  }
+  if (!(parts & 2)) return MO_OK;
   // weights: dW[co][s*32+c] = sum_p dm[p][co] srcs[s][p][c]
   MoOperand A2 = op_simple(dh, 32, P, 32);                // KROWS rows = k = p, cols = m = co
   A2.seg[0].drop_seed = drop_seed; A2.seg[0].drop_thresh = drop_thresh; A2.seg[0].drop_scale = drop_scale;

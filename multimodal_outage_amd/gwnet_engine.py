@@ -61,6 +61,7 @@ class GwnetConfig:
 # node-axis product is bracketed by HIP events on the launching stream and appended as
 # (name, algorithmic_flops, start_event, end_event).
 PROFILE = None
+SERIAL = False   # True: disable the side-stream overlap (bench.py's un-contended roofline pass)
 
 
 def _dense(name, N, J, *args):
@@ -133,11 +134,40 @@ _SIDE = {}
 
 
 def _side_stream(dev):
-    """One side HIP stream per device for the dense adaptive-adjacency branch."""
-    key = (dev.type, dev.index)
+    """Side HIP streams (one per device and role): the dense adaptive-adjacency branch, the weight gradients."""
+    role = 'dense'
+    if isinstance(dev, tuple):
+        dev, role = dev
+    key = (dev.type, dev.index, role)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
+
+
+class _WgradLane:
+    """Weight/bias-gradient kernels are off the data-flow critical path of the backward pass: they run on a
+    second side stream beside the next kernels of the main chain and are joined once at the end.  Tensors
+    allocated on the main stream and read here are protected with record_stream; workspaces are allocated
+    under the side stream."""
+
+    def __init__(self, dev, enabled):
+        self.main = torch.cuda.current_stream()
+        self.side = _side_stream((dev, 'wgrad')) if enabled else None
+
+    def run(self, fn, reads=()):
+        if self.side is None:
+            fn()
+            return
+        self.side.wait_stream(self.main)
+        for t in reads:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
 
 
 def _spmm(csr, n, X, Y, J, beta):
@@ -208,7 +238,7 @@ class GwnetFunction(torch.autograd.Function):
             if cfg.gcn:
                 # the dense (adaptive, MFMA-bound) branch runs on a side HIP stream beside the sparse
                 # (static CSR, HBM-bound) branch; both only read g and are joined in front of the mlp
-                side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap) else None
+                side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap and not SERIAL) else None
                 dense_out = []
                 if cfg.adaptive:
                     x1 = _e(P, 32, dev)
@@ -284,6 +314,7 @@ class GwnetFunction(torch.autograd.Function):
         st = L.stream()
         grads = {k: None for k in cfg.names}
         gout = cfg.grad_out or {}
+        lane = _WgradLane(dev, cfg.overlap and not SERIAL)
 
         def gbuf(name, like=None, shape=None):
             """Gradient destination: the trainer's flat-buffer view when registered, else a new tensor."""
@@ -304,14 +335,16 @@ class GwnetFunction(torch.autograd.Function):
         skip, r1 = ctx.skip, ctx.r1
         ws = ws_for(max(cfg.Ce, cfg.Cout), max(cfg.Ce, cfg.Cs), P_f)
         gW2 = gbuf('end_conv_2.weight', p['end_conv_2.weight']); gb2 = gbuf('end_conv_2.bias', p['end_conv_2.bias'])
-        L.call('mo_conv1x1_bwd_weight', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(r1), cfg.Ce, 0, 0, 0, 0,
-               L.ptr(gW2), L.ptr(gb2), L.ptr(ws), st)
+        lane.run(lambda: L.call('mo_conv1x1_bwd_weight', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(r1), cfg.Ce, 0, 0, 0, 0,
+                                L.ptr(gW2), L.ptr(gb2), L.ptr(ws_for(cfg.Cout, cfg.Ce, P_f)), L.stream()),
+                 reads=(dy_int,))
         da1 = _e(P_f, cfg.Ce, dev)
         L.call('mo_conv1x1_bwd_data', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(p['end_conv_2.weight']), cfg.Ce,
                L.ptr(da1), 0, 0, 0, L.ptr(r1), 0, st)
         gW1 = gbuf('end_conv_1.weight', p['end_conv_1.weight']); gb1 = gbuf('end_conv_1.bias', p['end_conv_1.bias'])
-        L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, P_f, L.ptr(skip), cfg.Cs, 0, 0, 0, 1,
-               L.ptr(gW1), L.ptr(gb1), L.ptr(ws), st)
+        lane.run(lambda: L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, P_f, L.ptr(skip), cfg.Cs, 0, 0, 0, 1,
+                                L.ptr(gW1), L.ptr(gb1), L.ptr(ws_for(cfg.Ce, cfg.Cs, P_f)), L.stream()),
+                 reads=(da1,))
         dskip = _e(P_f, cfg.Cs, dev)
         L.call('mo_conv1x1_bwd_data', L.ptr(da1), cfg.Ce, P_f, L.ptr(p['end_conv_1.weight']), cfg.Cs,
                L.ptr(dskip), 0, 0, 0, L.ptr(skip), 0, st)
@@ -352,17 +385,22 @@ class GwnetFunction(torch.autograd.Function):
                     W = p[f'residual_convs.{i}.weight']
                     kW, kb = f'residual_convs.{i}.weight', f'residual_convs.{i}.bias'
                 gW = gbuf(kW, W); gbm = gbuf(kb, shape=(32,))
-                wsm = ws_for(32, 32 * ns, P)
                 dx2_bf = (torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
                           if (ly['bf'] is not None and cfg.gcn and cfg.adaptive) else None)
                 L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
-                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), L.ptr(wsm), L.ptr(dx2_bf), st)
+                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), None, L.ptr(dx2_bf), 1, st)
+
+                def _mlp_w(dh=dh, srcs=srcs, dsrcs=dsrcs, ns=ns, W=W, P=P, ly=ly, gW=gW, gbm=gbm):
+                    L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
+                           ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm),
+                           L.ptr(ws_for(32, 32 * ns, P)), None, 2, L.stream())
+                lane.run(_mlp_w, reads=(dh,))
                 grads[kW], grads[kb] = gW, gbm
                 dg = dsrcs[0]
                 k = 1
                 if cfg.gcn:
                     ka = 1 + 2 * len(statics)
-                    side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap) else None
+                    side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap and not SERIAL) else None
                     if cfg.adaptive:
                         # dense branch, part 1 (does not touch dg): dx1 += adp.dx2 ; dA += x1.dx2^T ; dA += g.dx1^T
                         x1 = srcs[ka]
@@ -406,9 +444,9 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_conv1x1_bwd_data', L.ptr(dskip), cfg.Cs, P_f, L.ptr(Ws), 32, L.ptr(dg), Tf, Tout,
                    Tout - Tf, None, beta, st)
             gWs = gbuf(f'skip_convs.{i}.weight', Ws)
-            wss = ws_for(cfg.Cs, 32, P_f)
-            L.call('mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
-                   L.ptr(gWs), None, L.ptr(wss), st)
+            lane.run(lambda g=g, gWs=gWs, Tout=Tout: L.call(
+                'mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
+                L.ptr(gWs), None, L.ptr(ws_for(cfg.Cs, 32, P_f)), L.stream()), reads=(dskip,))
             grads[f'skip_convs.{i}.weight'] = gWs
             sb = gout.get(f'skip_convs.{i}.bias')
             if sb is not None:
@@ -421,11 +459,18 @@ class GwnetFunction(torch.autograd.Function):
             gWf = gbuf(f'filter_convs.{i}.weight', p[f'filter_convs.{i}.weight']); gWg = gbuf(f'gate_convs.{i}.weight', p[f'gate_convs.{i}.weight'])
             gbf = gbuf(f'filter_convs.{i}.bias', shape=(32,)); gbg = gbuf(f'gate_convs.{i}.bias', shape=(32,))
             dpre = _e(P, 64, dev)
-            ws2 = ws_for(64, 32 * K, P)
+            ws2_dummy = torch.empty(16, device=dev, dtype=torch.float32)
             L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
                    L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, cfg.dil[i], G,
                    Tin, L.ptr(dg), L.ptr(dh), L.ptr(du), L.ptr(gWf), L.ptr(gWg), L.ptr(gbf), L.ptr(gbg),
-                   L.ptr(dpre), L.ptr(ws2), st)
+                   L.ptr(dpre), L.ptr(ws2_dummy), 1, st)
+
+            def _tcn_w(ly=ly, i=i, Tin=Tin, P=P, dg=dg, dpre=dpre, gWf=gWf, gWg=gWg, gbf=gbf, gbg=gbg):
+                L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
+                       L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, cfg.dil[i], G,
+                       Tin, L.ptr(dg), None, None, L.ptr(gWf), L.ptr(gWg), L.ptr(gbf), L.ptr(gbg),
+                       L.ptr(dpre), L.ptr(ws_for(64, 32 * K, P)), 2, L.stream())
+            lane.run(_tcn_w, reads=(dpre, dg))
             grads[f'filter_convs.{i}.weight'], grads[f'filter_convs.{i}.bias'] = gWf, gbf
             grads[f'gate_convs.{i}.weight'], grads[f'gate_convs.{i}.bias'] = gWg, gbg
             dxo = du
@@ -434,9 +479,9 @@ class GwnetFunction(torch.autograd.Function):
         pad = Tp - T
         Wst = p['start_conv.weight']
         gWst = gbuf('start_conv.weight', Wst); gbst = gbuf('start_conv.bias', shape=(32,))
-        wst = ws_for(32, cfg.Cin, G * Tp)
-        L.call('mo_conv1x1_bwd_weight', L.ptr(dxo), 32, G * Tp, L.ptr(ctx.x_int), cfg.Cin, Tp, T, -pad, 0,
-               L.ptr(gWst), L.ptr(gbst), L.ptr(wst), st)
+        lane.run(lambda: L.call('mo_conv1x1_bwd_weight', L.ptr(dxo), 32, G * Tp, L.ptr(ctx.x_int), cfg.Cin, Tp, T, -pad,
+                                0, L.ptr(gWst), L.ptr(gbst), L.ptr(ws_for(32, cfg.Cin, G * Tp)), L.stream()),
+                 reads=(dxo,))
         grads['start_conv.weight'], grads['start_conv.bias'] = gWst, gbst
         dx = None
         if ctx.x_needs_grad:
@@ -460,6 +505,7 @@ class GwnetFunction(torch.autograd.Function):
                 gE1 = torch.zeros_like(E1); gE2 = torch.zeros_like(E2)
             grads['nodevec1'], grads['nodevec2'] = gE1, gE2
 
+        lane.join()
         # gradients written straight into registered flat-buffer views are not handed to autograd
         return (None, None, None, None, dx) + tuple(
             None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)

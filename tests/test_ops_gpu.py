@@ -221,7 +221,7 @@ def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine):
     ws2 = torch.empty(lib.mo_wgrad_ws_floats(64, 32 * K, G * Tout), device='cuda')
     L.call('mo_tcn_bwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
            L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(dev(nbtc(dg))), L.ptr(dev(nbtc(dres))), L.ptr(du),
-           L.ptr(dWf), L.ptr(dWg), L.ptr(dbf), L.ptr(dbg), L.ptr(dpre), L.ptr(ws2), L.stream())
+           L.ptr(dWf), L.ptr(dWg), L.ptr(dbf), L.ptr(dbg), L.ptr(dpre), L.ptr(ws2), 3, L.stream())
     close(du, nbtc(du_ref), what='du')
     close(dWf, Wf.grad, what='dWf')
     close(dWg, Wg.grad, what='dWg')
@@ -363,7 +363,7 @@ def test_gcn_mlp_bn(L, B, N, Tin, Tout, ns, drop, affine):
     wsm = torch.empty(lib.mo_wgrad_ws_floats(32, 32 * ns, P), device='cuda')
     dlast_bf = torch.empty(P, 32, device='cuda', dtype=torch.bfloat16)
     L.call('mo_gcn_mlp_bwd', L.ptr(dev(dhh)), L.ptr_array(sd), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P,
-           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), L.ptr(dlast_bf), L.stream())
+           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), L.ptr(dlast_bf), 3, L.stream())
     assert torch.equal(dlast_bf.cpu(), dsrcs[ns - 1].cpu().to(torch.bfloat16))
     for s in range(ns):
         close(dsrcs[s], dcat[:, 32 * s:32 * (s + 1)], what=f'dsrc{s}')
