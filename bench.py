@@ -59,7 +59,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(supports, max_steps=3, batch=1, budget_s=25.0):
+def cpu_baseline(supports, max_steps=5, batch=4, budget_s=25.0):
     """The CPU oracle (a port of graph_wavenet.py:191-254: dense einsum supports, unfused ops) on the
     host cores: fwd + MSE + bwd + Adam on batches of `batch` windows of the same workload; bounded
     to about `budget_s` seconds of CPU work."""
@@ -108,7 +108,7 @@ def main():
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16',
                     help='operand type of the dense adaptive-adjacency products (fp32 accumulate either way)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=5)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
