@@ -146,64 +146,79 @@ __device__ __forceinline__ float4 mo_fetch4(const MoSeg* segs, int nseg, int seg
   return v;
 }
 
+// The three image-source fetchers are branch-free: indices are clamped, every load is issued
+// unconditionally and the result is masked, so the NV fetches of a tile stay in flight together.
 __device__ __forceinline__ float4 mo_fetch4_im2col(const MoSeg* segs, const MoGeom& g, int rows, int cols, int q,
                                                    int p) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (q >= rows || p >= cols) return v;
-  const int ci = q / 9, tap = q - ci * 9;
+  const bool inb = (q < rows) & (p < cols);
+  const int qq = inb ? q : 0, pp = inb ? p : 0;
+  const int ci = qq / 9, tap = qq - ci * 9;
   const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
   const int s = (ci >= g.C0) ? 1 : 0;
   const int c = ci - (s ? g.C0 : 0);
   const int Cs = s ? g.C1 : g.C0;
   const MoSeg& sg = segs[s];
-  const int img = p / g.HW, pix = p - img * g.HW;
+  const float* bptr = sg.ptr;
+  const float* scp = sg.scale;
+  const float* shp = sg.shift;
+  const int sld = sg.ld, srelu = sg.relu;
+  const int img = pp / g.HW, pix = pp - img * g.HW;
   const int y = pix / g.W, x = pix - y * g.W;
   const int yy = y + ky;
-  if (yy < 0 || yy >= g.H) return v;
-  const float* base = sg.ptr + (long)img * sg.ld + (long)c * g.HW + yy * g.W;
-  float sc = 1.f, sh = 0.f;
-  const bool aff = sg.scale != nullptr;
-  if (aff) { const int grp = img / g.gsize; sc = mo_gload(sg.scale + grp * Cs + c); sh = mo_gload(sg.shift + grp * Cs + c); }
-  float* vp = &v.x;
+  const bool rowok = inb & (yy >= 0) & (yy < g.H);
+  const int yyc = min(max(yy, 0), g.H - 1);
+  const float* base = bptr + (long)img * sld + (long)c * g.HW + yyc * g.W;
+  const bool aff = scp != nullptr;
+  const int grp = img / g.gsize;
+  const float sc = aff ? mo_gload((aff ? scp : bptr) + (aff ? grp * Cs + c : 0)) : 1.f;
+  const float sh = aff ? mo_gload((aff ? shp : bptr) + (aff ? grp * Cs + c : 0)) : 0.f;
+  float t[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int xx = x + j + kx;
-    if (xx >= 0 && xx < g.W) {
-      float t = mo_gload(base + xx);
-      if (aff) t = t * sc + sh;
-      if (sg.relu) t = fmaxf(t, 0.f);
-      vp[j] = t;
-    }
+    const int xc = min(max(xx, 0), g.W - 1);
+    float u = mo_gload(base + xc) * sc + sh;
+    u = srelu ? fmaxf(u, 0.f) : u;
+    t[j] = (rowok & (xx >= 0) & (xx < g.W)) ? u : 0.f;
   }
-  return v;
+  return make_float4(t[0], t[1], t[2], t[3]);
 }
 
 __device__ __forceinline__ float4 mo_fetch4_nchw(const MoSeg* segs, const MoGeom& g, int rows, int cols, int c,
                                                  int p) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c >= rows || p >= cols) return v;
+  const bool inb = (c < rows) & (p < cols);
+  const int cq = inb ? c : 0, pp = inb ? p : 0;
   const MoSeg& sg = segs[0];
-  const int img = p / g.HW, pix = p - img * g.HW;
-  v = mo_gload(reinterpret_cast<const float4*>(sg.ptr + (long)img * sg.ld + (long)c * g.HW + pix));
-  if (sg.scale) {
-    const int grp = img / g.gsize;
-    const float sc = mo_gload(sg.scale + grp * g.C0 + c), sh = mo_gload(sg.shift + grp * g.C0 + c);
-    v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
-  }
-  if (sg.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  const float* bptr = sg.ptr;
+  const float* scp = sg.scale;
+  const float* shp = sg.shift;
+  const int sld = sg.ld, srelu = sg.relu;
+  const int img = pp / g.HW, pix = pp - img * g.HW;
+  float4 v = mo_gload(reinterpret_cast<const float4*>(bptr + (long)img * sld + (long)cq * g.HW + pix));
+  const bool aff = scp != nullptr;
+  const int grp = img / g.gsize;
+  const float sc = aff ? mo_gload((aff ? scp : bptr) + (aff ? grp * g.C0 + cq : 0)) : 1.f;
+  const float sh = aff ? mo_gload((aff ? shp : bptr) + (aff ? grp * g.C0 + cq : 0)) : 0.f;
+  v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+  if (srelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
   return v;
 }
 
 __device__ __forceinline__ float4 mo_fetch4_convt(const MoSeg* segs, const MoGeom& g, int rows, int cols, int r,
                                                   int p) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (r >= rows || p >= cols) return v;
+  const bool inb = (r < rows) & (p < cols);
+  const int rq = inb ? r : 0, pp = inb ? p : 0;
   const MoSeg& sg = segs[0];
-  const int co = r >> 2, ky = (r >> 1) & 1, kx = r & 1;
-  const int img = p / g.HW, pix = p - img * g.HW;
+  const float* bptr = sg.ptr;
+  const int sld = sg.ld;
+  const int co = rq >> 2, ky = (rq >> 1) & 1, kx = rq & 1;
+  const int img = pp / g.HW, pix = pp - img * g.HW;
   const int y = pix / g.W, x = pix - y * g.W;
-  const float* base = sg.ptr + (long)img * sg.ld + (long)co * 4 * g.HW + (long)(2 * y + ky) * 2 * g.W + 2 * x + kx;
+  const float* base = bptr + (long)img * sld + (long)co * 4 * g.HW + (long)(2 * y + ky) * 2 * g.W + 2 * x + kx;
+  float4 v;
   v.x = mo_gload(base); v.y = mo_gload(base + 2); v.z = mo_gload(base + 4); v.w = mo_gload(base + 6);
+  if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
   return v;
 }
 
