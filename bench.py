@@ -104,9 +104,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='windows per GPU per step (weak scaling)')
+    ap.add_argument('--batch', type=int, default=64, help='windows per GPU per step (weak scaling)')
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16',
                     help='operand type of the dense adaptive-adjacency products (fp32 accumulate either way)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to rehearse "
+                    "the multi-rank control flow on a one-GPU box)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
     args = ap.parse_args()
@@ -117,8 +119,12 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
