@@ -65,7 +65,7 @@ static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M
   if (M <= 0 || N <= 0) return MO_OK;
   dim3 grid(mo_cdiv(M, BM), mo_cdiv(N, BN), nz);
   dim3 block(WM * WN * 64);
-  MoGeom G = {0, 0, 0, 1, 0, 0};
+  MoGeom G = {0, 0, 0, 1, 0, 0, -1, -1};
   if (op_fast_ok(A) && op_fast_ok(B)) {
     const MoOperand An = op_norm(A), Bn = op_norm(B);
     hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI, MO_SRC_PLAIN, MO_SRC_PLAIN, 1>), grid,

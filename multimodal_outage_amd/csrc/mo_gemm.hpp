@@ -58,6 +58,7 @@ struct MoGeom {
   int H, W, HW;     // spatial size of the (low-resolution, for CONVT) pixel grid
   int gsize;        // images per BatchNorm group (the reference normalises per county call: `horizon` images)
   int C0, C1;       // channels of segment 0 / 1
+  int lw, lhw;      // log2(W), log2(HW) when powers of two (shift/mask pixel decomposition), else -1
 };
 
 struct MoEpi {
@@ -148,6 +149,19 @@ __device__ __forceinline__ float4 mo_fetch4(const MoSeg* segs, int nseg, int seg
 
 // The three image-source fetchers are branch-free: indices are clamped, every load is issued
 // unconditionally and the result is masked, so the NV fetches of a tile stay in flight together.
+// p -> (img, y, x): shifts and masks for power-of-two image sizes (all UNet levels), division otherwise
+__device__ __forceinline__ void mo_pix(const MoGeom& g, int p, int& img, int& y, int& x) {
+  if (g.lhw >= 0) {
+    img = p >> g.lhw;
+    const int pix = p & (g.HW - 1);
+    y = pix >> g.lw; x = pix & (g.W - 1);
+  } else {
+    img = p / g.HW;
+    const int pix = p - img * g.HW;
+    y = pix / g.W; x = pix - y * g.W;
+  }
+}
+
 __device__ __forceinline__ float4 mo_fetch4_im2col(const MoSeg* segs, const MoGeom& g, int rows, int cols, int q,
                                                    int p) {
   const bool inb = (q < rows) & (p < cols);
@@ -162,8 +176,8 @@ __device__ __forceinline__ float4 mo_fetch4_im2col(const MoSeg* segs, const MoGe
   const float* scp = sg.scale;
   const float* shp = sg.shift;
   const int sld = sg.ld, srelu = sg.relu;
-  const int img = pp / g.HW, pix = pp - img * g.HW;
-  const int y = pix / g.W, x = pix - y * g.W;
+  int img, y, x;
+  mo_pix(g, pp, img, y, x);
   const int yy = y + ky;
   const bool rowok = inb & (yy >= 0) & (yy < g.H);
   const int yyc = min(max(yy, 0), g.H - 1);
@@ -193,7 +207,8 @@ __device__ __forceinline__ float4 mo_fetch4_nchw(const MoSeg* segs, const MoGeom
   const float* scp = sg.scale;
   const float* shp = sg.shift;
   const int sld = sg.ld, srelu = sg.relu;
-  const int img = pp / g.HW, pix = pp - img * g.HW;
+  const int img = (g.lhw >= 0) ? (pp >> g.lhw) : (pp / g.HW);
+  const int pix = pp - img * g.HW;
   float4 v = mo_gload(reinterpret_cast<const float4*>(bptr + (long)img * sld + (long)cq * g.HW + pix));
   const bool aff = scp != nullptr;
   const int grp = img / g.gsize;
@@ -213,8 +228,8 @@ __device__ __forceinline__ float4 mo_fetch4_convt(const MoSeg* segs, const MoGeo
   const float* bptr = sg.ptr;
   const int sld = sg.ld;
   const int co = rq >> 2, ky = (rq >> 1) & 1, kx = rq & 1;
-  const int img = pp / g.HW, pix = pp - img * g.HW;
-  const int y = pix / g.W, x = pix - y * g.W;
+  int img, y, x;
+  mo_pix(g, pp, img, y, x);
   const float* base = bptr + (long)img * sld + (long)co * 4 * g.HW + (long)(2 * y + ky) * 2 * g.W + 2 * x + kx;
   float4 v;
   v.x = mo_gload(base); v.y = mo_gload(base + 2); v.z = mo_gload(base + 4); v.w = mo_gload(base + 6);
@@ -553,7 +568,8 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
     for (int j = 0; j < TN; ++j) {
       const int pcol = n0 + wn0 + j * 32 + fi;
       if (pcol >= N) continue;
-      const int img = pcol / G.HW, pix = pcol - img * G.HW;
+      const int img = (G.lhw >= 0) ? (pcol >> G.lhw) : (pcol / G.HW);
+      const int pix = pcol - img * G.HW;
       float* obase = E.out[0] + (long)img * E.ldo;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {

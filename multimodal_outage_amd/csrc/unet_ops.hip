@@ -94,8 +94,12 @@ static int uwgrad(const MoOperand& A, const MoOperand& B, const MoGeom& G, int M
   return mo_launch_status();
 }
 
+static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; }
 static MoGeom geom(int H, int W, int gsize, int C0, int C1) {
-  MoGeom g; g.H = H; g.W = W; g.HW = H * W; g.gsize = gsize < 1 ? 1 : gsize; g.C0 = C0; g.C1 = C1; return g;
+  MoGeom g; g.H = H; g.W = W; g.HW = H * W; g.gsize = gsize < 1 ? 1 : gsize; g.C0 = C0; g.C1 = C1;
+  g.lw = ilog2_exact(W); g.lhw = ilog2_exact(H * W);
+  if (g.lw < 0 || g.lhw < 0) { g.lw = -1; g.lhw = -1; }
+  return g;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -262,40 +266,51 @@ extern "C" int mo_nchw_stats(const float* y, long istride, int C, long n_img, in
 
 // group BatchNorm finalize: groups of gsize consecutive images; running stats updated group by group in
 // order (the reference's per-county, per-batch-element sequence of nn.BatchNorm2d calls)
-__global__ void group_bn_finalize_kernel(const float* __restrict__ stats, long n_img, int C, int gsize, int HW,
-                                         const float* gamma, const float* beta, float* running_mean,
-                                         float* running_var, float momentum, float eps, int training, float* scale,
-                                         float* shift, float* mean_out, float* rstd_out) {
+// stage A: one thread per (group, channel) -> mean / rstd / folded affine
+__global__ void group_bn_stats_kernel(const float* __restrict__ stats, long G, int C, int gsize, int HW,
+                                      const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, int training, float* scale, float* shift,
+                                      float* mean_out, float* rstd_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const long g = i / C; const int c = (int)(i - g * C);
+  float mean, var;
+  if (training) {
+    const double M = (double)gsize * HW;
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < gsize; ++j) {
+      const float* st = stats + ((g * gsize + j) * C + c) * 2;
+      s1 += st[0]; s2 += st[1];
+    }
+    double m = s1 / M, v = s2 / M - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
+  } else {
+    mean = running_mean[c]; var = running_var[c];
+  }
+  const float rstd = 1.f / sqrtf(var + eps);
+  scale[i] = gamma[c] * rstd;
+  shift[i] = beta[c] - mean * gamma[c] * rstd;
+  mean_out[i] = mean;
+  rstd_out[i] = rstd;
+}
+// stage B: running statistics receive G sequential momentum updates in group order (one thread per channel;
+// the biased variance is recovered from rstd: var = 1/rstd^2 - eps)
+__global__ void group_bn_running_kernel(const float* __restrict__ mean_g, const float* __restrict__ rstd_g, long G,
+                                        int C, int gsize, int HW, float momentum, float eps, float* running_mean,
+                                        float* running_var) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const long G = n_img / gsize;
   const double M = (double)gsize * HW;
+  const float unb = (M > 1.0) ? (float)(M / (M - 1.0)) : 1.f;
   float rm = running_mean[c], rv = running_var[c];
-  const float ga = gamma[c], be = beta[c];
   for (long g = 0; g < G; ++g) {
-    float mean, var;
-    if (training) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int j = 0; j < gsize; ++j) {
-        const float* st = stats + ((g * gsize + j) * C + c) * 2;
-        s1 += st[0]; s2 += st[1];
-      }
-      double m = s1 / M, v = s2 / M - m * m;
-      if (v < 0.0) v = 0.0;
-      mean = (float)m; var = (float)v;
-      double unb = (M > 1.0) ? v * M / (M - 1.0) : v;
-      rm = (1.f - momentum) * rm + momentum * mean;
-      rv = (1.f - momentum) * rv + momentum * (float)unb;
-    } else {
-      mean = rm; var = rv;
-    }
-    const float rstd = 1.f / sqrtf(var + eps);
-    scale[g * C + c] = ga * rstd;
-    shift[g * C + c] = be - mean * ga * rstd;
-    mean_out[g * C + c] = mean;
-    rstd_out[g * C + c] = rstd;
+    const float mean = mean_g[g * C + c], rs = rstd_g[g * C + c];
+    const float var = fmaxf(1.f / (rs * rs) - eps, 0.f);
+    rm = (1.f - momentum) * rm + momentum * mean;
+    rv = (1.f - momentum) * rv + momentum * (var * unb);
   }
-  if (training) { running_mean[c] = rm; running_var[c] = rv; }
+  running_mean[c] = rm; running_var[c] = rv;
 }
 extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int gsize, int HW, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float momentum,
@@ -303,8 +318,12 @@ extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int g
                                     void* stream) {
   MO_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && mean && rstd);
   MO_CHECK_ARG(C > 0 && gsize > 0 && n_img > 0 && (n_img % gsize) == 0 && (!training || stats));
-  hipLaunchKernelGGL(group_bn_finalize_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, ST(stream), stats, n_img, C, gsize, HW,
-                     gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd);
+  const long G = n_img / gsize;
+  hipLaunchKernelGGL(group_bn_stats_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, ST(stream), stats, G, C, gsize, HW,
+                     gamma, beta, running_mean, running_var, eps, training, scale, shift, mean, rstd);
+  if (training)
+    hipLaunchKernelGGL(group_bn_running_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, ST(stream), mean, rstd, G, C, gsize,
+                       HW, momentum, eps, running_mean, running_var);
   return mo_launch_status();
 }
 
@@ -394,24 +413,28 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
   }
   if (threadIdx.x == 0) { part[(img * C + c) * 2] = sm[0][0]; part[(img * C + c) * 2 + 1] = sm[1][0]; }
 }
-__global__ void unet_act_bwd_final_kernel(const float* __restrict__ part, long n_img, int C, int gsize, int HW,
-                                          float* __restrict__ k12 /* [G][C][2] */, float* dgamma, float* dbeta) {
+__global__ void unet_act_bwd_final_kernel(const float* __restrict__ part, long G, int C, int gsize, int HW,
+                                          float* __restrict__ k12 /* [G][C][2] */) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const long g = i / C; const int c = (int)(i - g * C);
+  const double M = (double)gsize * HW;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = 0; j < gsize; ++j) {
+    const float* p = part + ((g * gsize + j) * C + c) * 2;
+    s1 += p[0]; s2 += p[1];
+  }
+  k12[i * 2] = (float)(s1 / M);
+  k12[i * 2 + 1] = (float)(s2 / M);
+}
+__global__ void unet_act_bwd_param_kernel(const float* __restrict__ k12, long G, int C, int gsize, int HW,
+                                          float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const long G = n_img / gsize;
   const double M = (double)gsize * HW;
   double dg = 0.0, db = 0.0;
-  for (long g = 0; g < G; ++g) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int j = 0; j < gsize; ++j) {
-      const float* p = part + ((g * gsize + j) * C + c) * 2;
-      s1 += p[0]; s2 += p[1];
-    }
-    k12[(g * C + c) * 2] = (float)(s1 / M);
-    k12[(g * C + c) * 2 + 1] = (float)(s2 / M);
-    db += s1; dg += s2;
-  }
-  dgamma[c] = (float)dg; dbeta[c] = (float)db;
+  for (long g = 0; g < G; ++g) { db += k12[(g * C + c) * 2]; dg += k12[(g * C + c) * 2 + 1]; }
+  dgamma[c] = (float)(dg * M); dbeta[c] = (float)(db * M);
 }
 __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -448,8 +471,9 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   const int HW = H * Wd;
   hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img), dim3(HW >= 1024 ? 256 : 64), 0, st, y, istride,
                      C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part);
-  hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, part, n_img, C, gsize, HW, k12,
-                     dgamma, dbeta);
+  const long G = n_img / gsize;
+  hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, k12);
+  hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
   const long total = n_img * C * HW;
   hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
                      gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total);
