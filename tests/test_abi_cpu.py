@@ -80,3 +80,16 @@ def test_state_dict_schema_matches_reference():
     torch.manual_seed(0)
     b = gwnet('cpu')
     assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
+
+
+def test_aptinit_svd_initialisation():
+    """graph_wavenet.py:138-142: nodevec1/2 from the rank-10 SVD of aptinit."""
+    from multimodal_outage_amd.models.graph_wavenet import gwnet
+    torch.manual_seed(3)
+    A = torch.rand(30, 30)
+    g = gwnet('cpu', num_nodes=30, supports=[np.eye(30)], aptinit=A, in_dim=2, out_dim=2)
+    m, p, n = torch.svd(A)
+    e1 = torch.mm(m[:, :10], torch.diag(p[:10] ** 0.5))
+    e2 = torch.mm(torch.diag(p[:10] ** 0.5), n[:, :10].t())
+    assert torch.allclose(g.nodevec1, e1) and torch.allclose(g.nodevec2, e2)
+    assert g.supports_len == 2 and list(g.state_dict())[:2] == ['nodevec1', 'nodevec2']

@@ -179,3 +179,67 @@ def test_gwnet_bf16_dense_mode_close_to_fp32():
     for k in g32:
         s = float(g32[k].abs().max())
         assert float((g16[k] - g32[k]).abs().max()) <= 5e-2 * s + 1e-7, k
+
+
+VARIANTS = {
+    'gwnet_V_nogcn': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=230, gcn_bool=False, addaptadj=True),
+    'gwnet_V_static': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=240, gcn_bool=True, addaptadj=False),
+    'gwnet_V_k1': dict(B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, seed=250, gcn_bool=True, addaptadj=True),
+}
+
+
+@pytest.mark.parametrize('name', list(VARIANTS))
+def test_gwnet_constructor_variants_vs_golden(name):
+    """Constructor variants of graph_wavenet.py:101: gcn_bool=False (residual_convs), addaptadj=False, K=1."""
+    from multimodal_outage_amd.models.graph_wavenet import gwnet
+    cfg = VARIANTS[name]
+    G = golden(name)
+    A = P.knn_graph(20)
+    sup = [gwnet_ref.asym_adj(A), gwnet_ref.asym_adj(A.T)]
+    adaptive = cfg['gcn_bool'] and cfg['addaptadj']
+    m = gwnet('cpu', num_nodes=20, dropout=0.0, supports=sup, in_dim=cfg['in_dim'], out_dim=cfg['out_dim'],
+              kernel_size=cfg['K'], gcn_bool=cfg['gcn_bool'], addaptadj=cfg['addaptadj'])
+    schema = P.gwnet_schema(num_nodes=20, supports_len=2 + (1 if adaptive else 0), in_dim=cfg['in_dim'],
+                            out_dim=cfg['out_dim'], kernel_size=cfg['K'], gcn_bool=cfg['gcn_bool'],
+                            addaptadj=cfg['addaptadj'])
+    P.load_into(m, P.seeded_values(schema, cfg['seed']))
+    m = m.cuda().train()
+    x = rand(cfg['seed'] + 1, (cfg['B'], cfg['in_dim'], 20, cfg['T'])).cuda().requires_grad_(True)
+    y = m(x)
+    assert_close(y, G['y'], 1e-4, 1e-4, 'y')
+    loss = F.mse_loss(y, rand(cfg['seed'] + 2, tuple(y.shape)).cuda())
+    assert abs(loss.item() - float(G['loss'])) < 1e-4 * float(G['loss'])
+    loss.backward()
+    assert_close(x.grad, G['dx'], 1e-6, 1e-3, 'dx')
+    check_grads({k: v.grad for k, v in m.named_parameters()}, G, atol=2e-6, rtol=1e-3)
+    sd = m.state_dict()
+    for k in G.files:
+        if k.startswith('buf/'):
+            assert_close(sd[k[4:]].float(), G[k], 1e-5, 1e-4, k)
+
+
+def test_gwnet_supports_none_adaptive_only_vs_oracle():
+    """supports=None with addaptadj=True (graph_wavenet.py:130-133): the adaptive adjacency is the only support."""
+    from multimodal_outage_amd.models.graph_wavenet import gwnet
+    N = 24
+    m = gwnet('cpu', num_nodes=N, dropout=0.0, supports=None, in_dim=4, out_dim=3, kernel_size=2)
+    assert m.supports_len == 1 and m.gconv[0].mlp.mlp.weight.shape[1] == 3 * 32
+    schema = P.gwnet_schema(num_nodes=N, supports_len=1, in_dim=4, out_dim=3, kernel_size=2)
+    vals = P.seeded_values(schema, 260)
+    P.load_into(m, vals)
+    m = m.cuda().train()
+    p = P.as_param_dict(vals)
+    x = rand(261, (2, 4, N, 12))
+    xr = x.clone().requires_grad_(True)
+    yr = gwnet_ref.gwnet_forward(p, xr, supports=[], kernel_size=2)
+    tgt = rand(262, tuple(yr.shape))
+    F.mse_loss(yr, tgt).backward()
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    assert_close(y, yr.detach(), 1e-4, 1e-4, 'y')
+    F.mse_loss(y, tgt.cuda()).backward()
+    assert_close(xg.grad, xr.grad, 1e-6, 1e-3, 'dx')
+    for k, v in m.named_parameters():
+        if p[k].grad is not None:
+            s = float(p[k].grad.abs().max())
+            assert float((v.grad.cpu() - p[k].grad).abs().max()) <= 1e-3 * s + 1e-7, k

@@ -192,3 +192,33 @@ def test_metrics_restatement():
     assert abs(rmse.item() ** 2 - metrics_ref.mse(yh, y).item()) < 1e-6
     assert abs(mae.item() - (yh - y).abs().mean().item()) < 1e-7
     assert mape.item() > 0
+
+
+VARIANTS = {
+    'gwnet_V_nogcn': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=230, gcn_bool=False, addaptadj=True),
+    'gwnet_V_static': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=240, gcn_bool=True, addaptadj=False),
+    'gwnet_V_k1': dict(B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, seed=250, gcn_bool=True, addaptadj=True),
+}
+
+
+@pytest.mark.parametrize('name', list(VARIANTS))
+def test_gwnet_constructor_variants(name):
+    """gcn_bool=False (residual_convs path, graph_wavenet.py:245), addaptadj=False (:242-243), kernel_size=1."""
+    cfg = VARIANTS[name]
+    G = golden(name)
+    A = P.knn_graph(20)
+    sup = [torch.from_numpy(gwnet_ref.asym_adj(A)), torch.from_numpy(gwnet_ref.asym_adj(A.T))]
+    adaptive = cfg['gcn_bool'] and cfg['addaptadj']
+    schema = P.gwnet_schema(num_nodes=20, supports_len=2 + (1 if adaptive else 0), in_dim=cfg['in_dim'],
+                            out_dim=cfg['out_dim'], kernel_size=cfg['K'], gcn_bool=cfg['gcn_bool'],
+                            addaptadj=cfg['addaptadj'])
+    p = P.as_param_dict(P.seeded_values(schema, cfg['seed']))
+    x = rand(cfg['seed'] + 1, (cfg['B'], cfg['in_dim'], 20, cfg['T'])).requires_grad_(True)
+    y = gwnet_ref.gwnet_forward(p, x, supports=sup, kernel_size=cfg['K'], gcn_bool=cfg['gcn_bool'],
+                                addaptadj=cfg['addaptadj'])
+    assert_close(y, G['y'], 1e-5, 1e-5, 'y')
+    loss = F.mse_loss(y, rand(cfg['seed'] + 2, tuple(y.shape)))
+    assert abs(loss.item() - float(G['loss'])) < 1e-6
+    loss.backward()
+    assert_close(x.grad, G['dx'], 1e-6, 1e-4, 'dx')
+    check_grads({k: v.grad for k, v in p.items() if v.requires_grad}, G, atol=1e-6, rtol=1e-4)

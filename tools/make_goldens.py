@@ -56,13 +56,15 @@ def schema_of(module):
 
 
 def gwnet_case(name, *, B, N, T, in_dim, out_dim, K, static_supports, generic, seed, horizon=1,
-               dropout=0.0, train_steps=1):
+               dropout=0.0, train_steps=1, gcn_bool=True, addaptadj=True, aptinit=None):
     sup_t = [torch.from_numpy(s) for s in static_supports]
     ns = R.load_gwnet(generic, sup_t, n_counties=N)
     g = ns['gwnet']('cpu', num_nodes=N, dropout=dropout, supports=sup_t, in_dim=in_dim,
-                    out_dim=out_dim, horizon=horizon, kernel_size=K)
-    schema = P.gwnet_schema(num_nodes=N, supports_len=len(sup_t) + 1, in_dim=in_dim,
-                            out_dim=out_dim, kernel_size=K)
+                    out_dim=out_dim, horizon=horizon, kernel_size=K, gcn_bool=gcn_bool, addaptadj=addaptadj,
+                    aptinit=aptinit)
+    schema = P.gwnet_schema(num_nodes=N, supports_len=len(sup_t) + (1 if (gcn_bool and addaptadj) else 0),
+                            in_dim=in_dim, out_dim=out_dim, kernel_size=K, gcn_bool=gcn_bool,
+                            addaptadj=addaptadj)
     assert schema_of(g) == [(k, tuple(v)) for k, v in schema.items()], 'schema mismatch'
     P.load_into(g, P.seeded_values(schema, seed))
     g.train()
@@ -84,8 +86,9 @@ def gwnet_case(name, *, B, N, T, in_dim, out_dim, K, static_supports, generic, s
     with torch.no_grad():
         d['y_eval'] = g(x.detach()).numpy()
     # adaptive adjacency
-    with torch.no_grad():
-        d['adp'] = F.softmax(F.relu(torch.mm(g.nodevec1, g.nodevec2)), dim=1).numpy()
+    if gcn_bool and addaptadj:
+        with torch.no_grad():
+            d['adp'] = F.softmax(F.relu(torch.mm(g.nodevec1, g.nodevec2)), dim=1).numpy()
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
     print(name, 'loss', loss.item(), 'y', tuple(y.shape), 'none grads', len(d['none_grads']))
 
@@ -240,6 +243,17 @@ if __name__ == '__main__':
         # C1c: T longer than the receptive field (T_final > 1)
         gwnet_case('gwnet_C1c', B=2, N=20, T=16, in_dim=4, out_dim=6, K=2,
                    static_supports=[asym_adj(A20), asym_adj(A20.T)], generic=True, seed=220)
+    if 'variants' in which:
+        # constructor variants of graph_wavenet.py:101 -- no gcn (residual_convs path, :245), static supports
+        # only (addaptadj=False, :242-243), SVD-initialised adaptive embeddings (aptinit, :138-142)
+        A20 = P.knn_graph(20)
+        sup2 = [asym_adj(A20), asym_adj(A20.T)]
+        gwnet_case('gwnet_V_nogcn', B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, static_supports=sup2, generic=True,
+                   seed=230, gcn_bool=False)
+        gwnet_case('gwnet_V_static', B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, static_supports=sup2, generic=True,
+                   seed=240, addaptadj=False)
+        gwnet_case('gwnet_V_k1', B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, static_supports=sup2, generic=True,
+                   seed=250)
     if 'blocks' in which:
         unet_blocks_case()
     if 'csr' in which:
