@@ -360,7 +360,10 @@ __device__ __forceinline__ void mo_fill_aff(float* aff, const MoOperand& op, int
   }
 }
 
-__device__ __forceinline__ float mo_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+// sigmoid / tanh on the hardware exp and reciprocal (v_exp_f32, v_rcp_f32): ~1e-6 relative error, and an
+// order of magnitude fewer VALU instructions than the libm tanhf, which made the gate epilogues VALU-bound
+__device__ __forceinline__ float mo_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float mo_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
 
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI, int ASRC = MO_SRC_PLAIN,
           int BSRC = MO_SRC_PLAIN, int FAST = 0>
@@ -550,7 +553,7 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
         if (m >= M) continue;
-        const float f = tanhf(acc[i][0][r] + bf);
+        const float f = mo_tanh(acc[i][0][r] + bf);
         const float g = mo_sigmoid(acc[i][TN - 1][r] + bg);
         if (EPI == MO_EPI_GATE) {
           E.out[0][(long)m * E.ldo + c] = f * g;

@@ -140,7 +140,9 @@ def _side_stream(dev):
         dev, role = dev
     key = (dev.type, dev.index, role)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
+        # the dense branch holds one 128-KB-LDS workgroup per CU: give it dispatch priority over the
+        # HBM-bound kernels it runs beside, or it starves behind their many small workgroups
+        _SIDE[key] = torch.cuda.Stream(device=dev, priority=-1 if role == 'dense' else 0)
     return _SIDE[key]
 
 
