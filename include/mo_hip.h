@@ -28,6 +28,8 @@ extern "C" {
 
 const char* mo_strerror(int code);
 int mo_version(void);
+/* tuning switches for A/B measurements: "persist" (1: persistent skinny-K kernels; 0, default: one workgroup per tile) */
+int mo_set_option(const char* name, int value);
 
 /* ---- layout: graph_wavenet.py:189/:255 boundary, (B,C,N,T) <-> nbtc -------------------------- */
 int mo_nchw_to_nbtc(const float* x, float* y, int B, int C, int N, int T, void* stream);

@@ -59,6 +59,13 @@ static MoOperand op_norm(const MoOperand& o) {
   return r;
 }
 
+// resident-B capacity (k tiles) of the persistent kernel per tile configuration
+template <int BN, int BK> struct PersistNK { static constexpr int value = (BN <= 32) ? 8 : 4; };
+// Off by default: with one A tile in flight per workgroup and 2 workgroups per CU it measured 9 % SLOWER
+// end to end than one workgroup per tile (3 per CU) -- fewer bytes in flight per CU.  It needs a deeper A ring
+// before it pays; mo_set_option("persist", 1) enables it for A/B runs.
+static int g_persist = 0;
+
 template <int BM, int BN, int BK, int WM, int WN, int AM, int BMODE, int EPI>
 static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M, long N, int nz,
                   hipStream_t st) {
@@ -68,6 +75,17 @@ static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M
   MoGeom G = {0, 0, 0, 1, 0, 0, -1, -1};
   if (op_fast_ok(A) && op_fast_ok(B)) {
     const MoOperand An = op_norm(A), Bn = op_norm(B);
+    if constexpr (AM == MO_XROWS) {
+      constexpr int NKRES = PersistNK<BN, BK>::value;
+      const int K = An.cols;
+      const int mt = mo_cdiv(M, BM);
+      if (g_persist && nz == 1 && E.kchunk == 0 && mo_cdiv(K, BK) <= NKRES && mt >= 64) {
+        dim3 pgrid(mt < 512 ? mt : 512, mo_cdiv(N, BN), 1);     // 2 workgroups per CU walk the M tiles
+        hipLaunchKernelGGL((mo_conv_persist_kernel<BM, BN, BK, WM, WN, BMODE, EPI, NKRES>), pgrid, block, 0, st, An,
+                           Bn, E, G, mt);
+        return mo_launch_status();
+      }
+    }
     hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI, MO_SRC_PLAIN, MO_SRC_PLAIN, 1>), grid,
                        block, 0, st, An, Bn, E, G);
   } else {
@@ -75,6 +93,12 @@ static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M
                        block, 0, st, A, B, E, G);
   }
   return mo_launch_status();
+}
+
+extern "C" int mo_set_option(const char* name, int value) {
+  if (!name) return MO_EINVAL;
+  if (name[0] == 'p') { g_persist = value; return MO_OK; }   // "persist"
+  return MO_EINVAL;
 }
 
 // split-K planning for weight gradients: slabs of [M][N], K = P rows

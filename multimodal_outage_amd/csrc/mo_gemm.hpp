@@ -365,135 +365,14 @@ __device__ __forceinline__ void mo_fill_aff(float* aff, const MoOperand& op, int
 __device__ __forceinline__ float mo_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
 __device__ __forceinline__ float mo_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
 
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI, int ASRC = MO_SRC_PLAIN,
-          int BSRC = MO_SRC_PLAIN, int FAST = 0>
-__global__ void __launch_bounds__(WM* WN * 64)
-mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom G) {
-  constexpr int NT = WM * WN * 64;
-  constexpr int SM = BM / WM, SN = BN / WN;
-  constexpr int TM = SM / 32, TN = SN / 32;
-  static_assert(SM % 32 == 0 && SN % 32 == 0, "wave tile must be a multiple of 32x32");
-  using TA = MoLoader<BM, BK, NT, AMODE, ASRC, FAST>;
-  using TB = MoLoader<BN, BK, NT, BMODE, BSRC, FAST>;
-
-  __shared__ __attribute__((aligned(16))) float As[2][BK * TA::LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * TB::LD];
-  __shared__ MoSeg sA[MO_MAX_SEG];
-  __shared__ MoSeg sB[MO_MAX_SEG];
-  __shared__ float red[(EPI == MO_EPI_MLP) ? WM * WN * 64 : 1];
-  __shared__ __attribute__((aligned(16))) float affA[FAST ? MO_MAX_SEG * 64 : 4];
-  __shared__ __attribute__((aligned(16))) float affB[FAST ? MO_MAX_SEG * 64 : 4];
-
+template <int TM, int TN, int WM, int WN, int AMODE, int BMODE, int EPI>
+__device__ __forceinline__ void mo_epilogue(f32x16 (&acc)[TM][TN], const MoOperand& A, const MoOperand& B, const MoEpi& E,
+                                            const MoGeom& G, int m0, int n0, int wm0, int wn0, int tile_x,
+                                            float* red) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm0 = (wave / WN) * SM;
-  const int wn0 = (wave % WN) * SN;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-
-  // stage operand descriptors in LDS (segment index may vary per lane)
-  if (tid < MO_MAX_SEG) { sA[tid] = A.seg[tid]; sB[tid] = B.seg[tid]; }
-  // FAST path, uniform per operand: bit0 affine present, bit1 ReLU, bit2 dropout
-  int postA = 0, postB = 0;
-  if (FAST) {
-    for (int q = 0; q < MO_MAX_SEG; ++q) {
-      if (q < A.nseg && A.seg[q].scale) postA |= 1;
-      if (q < B.nseg && B.seg[q].scale) postB |= 1;
-    }
-    if (A.seg[0].relu) postA |= 2;
-    if (B.seg[0].relu) postB |= 2;
-    if (A.seg[0].drop_thresh) postA |= 4;
-    if (AMODE == MO_KROWS && E.colsum && blockIdx.y == 0) postA |= 8;
-    if (B.seg[0].drop_thresh) postB |= 4;
-    if (postA & 1) mo_fill_aff(affA, A, tid, NT);
-    if (postB & 1) mo_fill_aff(affB, B, tid, NT);
-  }
-  const int ToA = A.seg[0].To > 0 ? A.seg[0].To : 1, ToB = B.seg[0].To > 0 ? B.seg[0].To : 1;
-  const int shA = (A.segw == 64) ? 6 : 5, shB = (B.segw == 64) ? 6 : 5;
-  __syncthreads();
-
-  // logical extents: M, N from the x-direction of each operand, K from the k-direction
-  const int K = (AMODE == MO_KROWS) ? A.rows : A.cols;
-  int kbeg = 0, kend = K;
-  if (E.kchunk > 0) {
-    kbeg = blockIdx.z * E.kchunk;
-    kend = min(K, kbeg + E.kchunk);
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  TA la;
-  TB lb;
-  la.init(A, ToA, m0, tid);
-  lb.init(B, ToB, n0, tid);
-  const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-  // Split-K chunks end on BK multiples except the last, which ends at K == rows/cols, so the operand's
-  // own extent check bounds the k direction.
-  if (nk > 0) {
-    la.issue(sA, A, ToA, shA, G, m0, kbeg, tid);
-    lb.issue(sB, B, ToB, shB, G, n0, kbeg, tid);
-    la.finish(As[0], affA, sA, postA, tid);
-    lb.finish(Bs[0], affB, sB, postB, tid);
-  }
-  __syncthreads();
-
   const int fi = lane & 31, fk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      la.issue(sA, A, ToA, shA, G, m0, kbeg + (kt + 1) * BK, tid);
-      lb.issue(sB, B, ToB, shB, G, n0, kbeg + (kt + 1) * BK, tid);
-    }
-    const float* Ac = As[cur];
-    const float* Bc = Bs[cur];
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Ac[(2 * ks + fk) * TA::LD + wm0 + i * 32 + fi];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bc[(2 * ks + fk) * TB::LD + wn0 + j * 32 + fi];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      la.finish(As[cur ^ 1], affA, sA, postA, tid);
-      lb.finish(Bs[cur ^ 1], affB, sB, postB, tid);
-    }
-    __syncthreads();
-  }
-
-  if (FAST && AMODE == MO_KROWS && (postA & 8)) {
-    // column sums of A over this block's K range: threads with equal x4 hold partial sums of the same
-    // four columns; reduce the NT/(BM/4) k-lanes through LDS (the tile buffers are free now)
-    constexpr int XG = BM / 4, KL = NT / XG;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < TA::NV; ++i) { t.x += la.cs[i].x; t.y += la.cs[i].y; t.z += la.cs[i].z; t.w += la.cs[i].w; }
-    float* red2 = &As[0][0];
-    const int x4 = tid % XG, kl = tid / XG;
-    *reinterpret_cast<float4*>(&red2[kl * BM + 4 * x4]) = t;
-    __syncthreads();
-    if (tid < BM) {
-      float sacc = 0.f;
-#pragma unroll 4
-      for (int q = 0; q < KL; ++q) sacc += red2[q * BM + tid];
-      const int Mtot = A.cols;
-      if (m0 + tid < Mtot) E.colsum[(long)blockIdx.z * Mtot + m0 + tid] = sacc;
-    }
-    __syncthreads();
-  }
-
   // ---------------------------------------------------------------- epilogue
   const int M = (AMODE == MO_KROWS) ? A.cols : A.rows;
   const int N = (BMODE == MO_KROWS) ? B.cols : B.rows;
@@ -630,7 +509,250 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < WM * WN; ++w) t += red[w * 64 + tid];
-      E.partial[(long)blockIdx.x * 64 + tid] = t;
+      E.partial[(long)tile_x * 64 + tid] = t;
     }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI, int ASRC = MO_SRC_PLAIN,
+          int BSRC = MO_SRC_PLAIN, int FAST = 0>
+__global__ void __launch_bounds__(WM* WN * 64)
+mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom G) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int SM = BM / WM, SN = BN / WN;
+  constexpr int TM = SM / 32, TN = SN / 32;
+  static_assert(SM % 32 == 0 && SN % 32 == 0, "wave tile must be a multiple of 32x32");
+  using TA = MoLoader<BM, BK, NT, AMODE, ASRC, FAST>;
+  using TB = MoLoader<BN, BK, NT, BMODE, BSRC, FAST>;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK * TA::LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * TB::LD];
+  __shared__ MoSeg sA[MO_MAX_SEG];
+  __shared__ MoSeg sB[MO_MAX_SEG];
+  __shared__ float red[(EPI == MO_EPI_MLP) ? WM * WN * 64 : 1];
+  __shared__ __attribute__((aligned(16))) float affA[FAST ? MO_MAX_SEG * 64 : 4];
+  __shared__ __attribute__((aligned(16))) float affB[FAST ? MO_MAX_SEG * 64 : 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WN) * SM;
+  const int wn0 = (wave % WN) * SN;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // stage operand descriptors in LDS (segment index may vary per lane)
+  if (tid < MO_MAX_SEG) { sA[tid] = A.seg[tid]; sB[tid] = B.seg[tid]; }
+  // FAST path, uniform per operand: bit0 affine present, bit1 ReLU, bit2 dropout
+  int postA = 0, postB = 0;
+  if (FAST) {
+    for (int q = 0; q < MO_MAX_SEG; ++q) {
+      if (q < A.nseg && A.seg[q].scale) postA |= 1;
+      if (q < B.nseg && B.seg[q].scale) postB |= 1;
+    }
+    if (A.seg[0].relu) postA |= 2;
+    if (B.seg[0].relu) postB |= 2;
+    if (A.seg[0].drop_thresh) postA |= 4;
+    if (AMODE == MO_KROWS && E.colsum && blockIdx.y == 0) postA |= 8;
+    if (B.seg[0].drop_thresh) postB |= 4;
+    if (postA & 1) mo_fill_aff(affA, A, tid, NT);
+    if (postB & 1) mo_fill_aff(affB, B, tid, NT);
+  }
+  const int ToA = A.seg[0].To > 0 ? A.seg[0].To : 1, ToB = B.seg[0].To > 0 ? B.seg[0].To : 1;
+  const int shA = (A.segw == 64) ? 6 : 5, shB = (B.segw == 64) ? 6 : 5;
+  __syncthreads();
+
+  // logical extents: M, N from the x-direction of each operand, K from the k-direction
+  const int K = (AMODE == MO_KROWS) ? A.rows : A.cols;
+  int kbeg = 0, kend = K;
+  if (E.kchunk > 0) {
+    kbeg = blockIdx.z * E.kchunk;
+    kend = min(K, kbeg + E.kchunk);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TA la;
+  TB lb;
+  la.init(A, ToA, m0, tid);
+  lb.init(B, ToB, n0, tid);
+  const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  // Split-K chunks end on BK multiples except the last, which ends at K == rows/cols, so the operand's
+  // own extent check bounds the k direction.
+  if (nk > 0) {
+    la.issue(sA, A, ToA, shA, G, m0, kbeg, tid);
+    lb.issue(sB, B, ToB, shB, G, n0, kbeg, tid);
+    la.finish(As[0], affA, sA, postA, tid);
+    lb.finish(Bs[0], affB, sB, postB, tid);
+  }
+  __syncthreads();
+
+  const int fi = lane & 31, fk = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      la.issue(sA, A, ToA, shA, G, m0, kbeg + (kt + 1) * BK, tid);
+      lb.issue(sB, B, ToB, shB, G, n0, kbeg + (kt + 1) * BK, tid);
+    }
+    const float* Ac = As[cur];
+    const float* Bc = Bs[cur];
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ac[(2 * ks + fk) * TA::LD + wm0 + i * 32 + fi];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bc[(2 * ks + fk) * TB::LD + wn0 + j * 32 + fi];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      la.finish(As[cur ^ 1], affA, sA, postA, tid);
+      lb.finish(Bs[cur ^ 1], affB, sB, postB, tid);
+    }
+    __syncthreads();
+  }
+
+  if (FAST && AMODE == MO_KROWS && (postA & 8)) {
+    // column sums of A over this block's K range: threads with equal x4 hold partial sums of the same
+    // four columns; reduce the NT/(BM/4) k-lanes through LDS (the tile buffers are free now)
+    constexpr int XG = BM / 4, KL = NT / XG;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TA::NV; ++i) { t.x += la.cs[i].x; t.y += la.cs[i].y; t.z += la.cs[i].z; t.w += la.cs[i].w; }
+    float* red2 = &As[0][0];
+    const int x4 = tid % XG, kl = tid / XG;
+    *reinterpret_cast<float4*>(&red2[kl * BM + 4 * x4]) = t;
+    __syncthreads();
+    if (tid < BM) {
+      float sacc = 0.f;
+#pragma unroll 4
+      for (int q = 0; q < KL; ++q) sacc += red2[q * BM + tid];
+      const int Mtot = A.cols;
+      if (m0 + tid < Mtot) E.colsum[(long)blockIdx.z * Mtot + m0 + tid] = sacc;
+    }
+    __syncthreads();
+  }
+
+  mo_epilogue<TM, TN, WM, WN, AMODE, BMODE, EPI>(acc, A, B, E, G, m0, n0, wm0, wn0, (int)blockIdx.x, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant for the skinny-K channel contractions (1x1 convs, gated TCN, gcn mlp, their data
+// gradients): K <= NKRES*BK, so the whole B operand (weights) stays resident in LDS and each workgroup
+// walks M tiles grid-stride with the A prefetch running across tile boundaries.  The plain kernel pays
+// its prologue (descriptor staging, affine table, first tile round trip) once per 128 rows, which for
+// K = 32..224 is most of its life; here it is paid once per workgroup and the loads never drain.
+// A is XROWS (rows = positions) and both operands use the FAST loader (checked on the host).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WM, int WN, int BMODE, int EPI, int NKRES>
+__global__ void __launch_bounds__(WM* WN * 64)
+mo_conv_persist_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom G, int num_mtiles) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int SM = BM / WM, SN = BN / WN;
+  constexpr int TM = SM / 32, TN = SN / 32;
+  using TA = MoLoader<BM, BK, NT, MO_XROWS, MO_SRC_PLAIN, 1>;
+  using TB = MoLoader<BN, BK, NT, BMODE, MO_SRC_PLAIN, 1>;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK * TA::LD];
+  __shared__ __attribute__((aligned(16))) float Bres[NKRES][BK * TB::LD];
+  __shared__ MoSeg sA[MO_MAX_SEG];
+  __shared__ MoSeg sB[MO_MAX_SEG];
+  __shared__ float red[(EPI == MO_EPI_MLP) ? WM * WN * 64 : 1];
+  __shared__ __attribute__((aligned(16))) float affA[MO_MAX_SEG * 64];
+  __shared__ __attribute__((aligned(16))) float affB[MO_MAX_SEG * 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WN) * SM;
+  const int wn0 = (wave % WN) * SN;
+  const int n0 = blockIdx.y * BN;
+
+  if (tid < MO_MAX_SEG) { sA[tid] = A.seg[tid]; sB[tid] = B.seg[tid]; }
+  int postA = 0, postB = 0;
+  for (int q = 0; q < MO_MAX_SEG; ++q) {
+    if (q < A.nseg && A.seg[q].scale) postA |= 1;
+    if (q < B.nseg && B.seg[q].scale) postB |= 1;
+  }
+  if (A.seg[0].relu) postA |= 2;
+  if (B.seg[0].relu) postB |= 2;
+  if (A.seg[0].drop_thresh) postA |= 4;
+  if (B.seg[0].drop_thresh) postB |= 4;
+  if (postA & 1) mo_fill_aff(affA, A, tid, NT);
+  if (postB & 1) mo_fill_aff(affB, B, tid, NT);
+  const int ToA = A.seg[0].To > 0 ? A.seg[0].To : 1, ToB = B.seg[0].To > 0 ? B.seg[0].To : 1;
+  const int shA = (A.segw == 64) ? 6 : 5, shB = (B.segw == 64) ? 6 : 5;
+  __syncthreads();
+
+  const int K = A.cols;
+  const int nk = (K + BK - 1) / BK;     // <= NKRES (host)
+  TA la;
+  TB lb;
+  lb.init(B, ToB, n0, tid);
+  for (int kt = 0; kt < nk; ++kt) {     // resident B: loaded once per workgroup
+    lb.issue(sB, B, ToB, shB, G, n0, kt * BK, tid);
+    lb.finish(Bres[kt], affB, sB, postB, tid);
+  }
+  int mt = blockIdx.x;
+  if (mt < num_mtiles) {
+    la.init(A, ToA, mt * BM, tid);
+    la.issue(sA, A, ToA, shA, G, mt * BM, 0, tid);
+    la.finish(As[0], affA, sA, postA, tid);
+  }
+  __syncthreads();
+
+  const int fi = lane & 31, fk = lane >> 5;
+  int it = 0;
+  for (; mt < num_mtiles; mt += gridDim.x) {
+    const int m0 = mt * BM;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      const int cur = it & 1;
+      const bool last_k = (kt + 1 == nk);
+      const int nmt = mt + gridDim.x;
+      const bool has_next = !last_k || (nmt < num_mtiles);
+      if (has_next) {
+        if (last_k) {                   // first k-tile of this workgroup's next M tile
+          la.init(A, ToA, nmt * BM, tid);
+          la.issue(sA, A, ToA, shA, G, nmt * BM, 0, tid);
+        } else {
+          la.issue(sA, A, ToA, shA, G, m0, (kt + 1) * BK, tid);
+        }
+      }
+      const float* Ac = As[cur];
+      const float* Bc = Bres[kt];
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = Ac[(2 * ks + fk) * TA::LD + wm0 + i * 32 + fi];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bc[(2 * ks + fk) * TB::LD + wn0 + j * 32 + fi];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (has_next) la.finish(As[cur ^ 1], affA, sA, postA, tid);
+      __syncthreads();
+    }
+    mo_epilogue<TM, TN, WM, WN, MO_XROWS, BMODE, EPI>(acc, A, B, E, G, m0, n0, wm0, wn0, mt, red);
   }
 }
