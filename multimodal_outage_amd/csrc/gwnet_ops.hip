@@ -86,7 +86,9 @@ static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M
         return mo_launch_status();
       }
     }
-    hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI, MO_SRC_PLAIN, MO_SRC_PLAIN, 1>), grid,
+    // skinny-K row contractions (tiles of 128 x <=64): single-buffered LDS, more workgroups per CU
+    constexpr int NBUF = (AM == MO_XROWS && BN <= 64) ? 1 : 2;
+    hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI, MO_SRC_PLAIN, MO_SRC_PLAIN, 1, NBUF>), grid,
                        block, 0, st, An, Bn, E, G);
   } else {
     hipLaunchKernelGGL((mo_gemm_kernel<BM, BN, BK, WM, WN, AM, BMODE, EPI, MO_SRC_PLAIN, MO_SRC_PLAIN, 0>), grid,

@@ -514,8 +514,11 @@ __device__ __forceinline__ void mo_epilogue(f32x16 (&acc)[TM][TN], const MoOpera
   }
 }
 
+// NBUF = 2: double-buffered LDS, one barrier per k-tile.  NBUF = 1: a single LDS tile pair and two barriers
+// per k-tile -- half the LDS, so more workgroups per CU; for the skinny-K, latency-bound contractions the
+// bytes in flight per CU (workgroups x one tile each) matter more than the extra barrier.
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int EPI, int ASRC = MO_SRC_PLAIN,
-          int BSRC = MO_SRC_PLAIN, int FAST = 0>
+          int BSRC = MO_SRC_PLAIN, int FAST = 0, int NBUF = 2>
 __global__ void __launch_bounds__(WM* WN * 64)
 mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom G) {
   constexpr int NT = WM * WN * 64;
@@ -525,8 +528,8 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
   using TA = MoLoader<BM, BK, NT, AMODE, ASRC, FAST>;
   using TB = MoLoader<BN, BK, NT, BMODE, BSRC, FAST>;
 
-  __shared__ __attribute__((aligned(16))) float As[2][BK * TA::LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * TB::LD];
+  __shared__ __attribute__((aligned(16))) float As[NBUF][BK * TA::LD];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * TB::LD];
   __shared__ MoSeg sA[MO_MAX_SEG];
   __shared__ MoSeg sB[MO_MAX_SEG];
   __shared__ float red[(EPI == MO_EPI_MLP) ? WM * WN * 64 : 1];
@@ -595,7 +598,7 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
 
   const int fi = lane & 31, fk = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+    const int cur = (NBUF == 2) ? (kt & 1) : 0;
     if (kt + 1 < nk) {
       la.issue(sA, A, ToA, shA, G, m0, kbeg + (kt + 1) * BK, tid);
       lb.issue(sB, B, ToB, shB, G, n0, kbeg + (kt + 1) * BK, tid);
@@ -615,9 +618,10 @@ mo_gemm_kernel(const MoOperand A, const MoOperand B, const MoEpi E, const MoGeom
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (NBUF == 1) __syncthreads();      // everyone is done reading the single tile pair
     if (kt + 1 < nk) {
-      la.finish(As[cur ^ 1], affA, sA, postA, tid);
-      lb.finish(Bs[cur ^ 1], affB, sB, postB, tid);
+      la.finish(As[(NBUF == 2) ? (cur ^ 1) : 0], affA, sA, postA, tid);
+      lb.finish(Bs[(NBUF == 2) ? (cur ^ 1) : 0], affB, sB, postB, tid);
     }
     __syncthreads();
   }
