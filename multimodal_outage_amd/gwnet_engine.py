@@ -415,14 +415,40 @@ class GwnetFunction(torch.autograd.Function):
                                 g_bf, x1_bf = ly['bf']
                                 dx1_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
                                 _adj_prod(ctx.adp_bf, dx2_bf, dx1, N, J, 1, dx1_bf)
-                                _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
-                                _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
+                                # only dx1 is needed by the main chain; the two dA accumulations keep running
+                                # on the side stream beside the rest of this layer's backward
+                                if side is not None:
+                                    dx1_ready = torch.cuda.Event()
+                                    dx1_ready.record(side)
+                                    gs = _side_stream((dev, 'dagrad'))     # a third stream: keeps the dense
+                                    gs.wait_event(dx1_ready)               # stream free for the next layer
+                                    for t_ in (dx2_bf, dx1_bf):
+                                        t_.record_stream(gs)
+                                    with torch.cuda.stream(gs):
+                                        _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
+                                        _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
+                                else:
+                                    _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
+                                    _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
                             else:
                                 sst = L.stream()
                                 _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, sst)
-                                _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
-                                       1 if dAdp_started else 0, sst)
-                                _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, sst)
+                                if side is not None:
+                                    dx1_ready = torch.cuda.Event()
+                                    dx1_ready.record(side)
+                                    gs = _side_stream((dev, 'dagrad'))
+                                    gs.wait_event(dx1_ready)
+                                    for t_ in (dx1, dx2):
+                                        t_.record_stream(gs)
+                                    with torch.cuda.stream(gs):
+                                        _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
+                                               1 if dAdp_started else 0, L.stream())
+                                        _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1,
+                                               L.stream())
+                                else:
+                                    _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
+                                           1 if dAdp_started else 0, sst)
+                                    _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, sst)
                             dAdp_started = True
                     for s in statics:
                         dx1s, dx2s = dsrcs[k], dsrcs[k + 1]
@@ -431,7 +457,7 @@ class GwnetFunction(torch.autograd.Function):
                         k += 2
                     if cfg.adaptive:
                         if side is not None:
-                            torch.cuda.current_stream().wait_stream(side)
+                            torch.cuda.current_stream().wait_event(dx1_ready)
                         # dense branch, part 2: dg += adp.dx1 (after the sparse accumulations into dg)
                         if ly['bf'] is not None:
                             _adj_prod(ctx.adp_bf, dx1_bf, dg, N, J, 1)
@@ -494,6 +520,8 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_nbtc_to_nchw', L.ptr(dx_int), L.ptr(dx), B, cfg.Cin, N, T, st)
 
         # ---- adaptive adjacency (graph_wavenet.py:202)
+        if dAdp is not None and cfg.overlap and not SERIAL and statics:
+            torch.cuda.current_stream().wait_stream(_side_stream((dev, 'dagrad')))   # the deferred dA accumulations
         if dAdp is not None:
             E1, E2 = p['nodevec1'], p['nodevec2']
             R = E1.shape[1]
