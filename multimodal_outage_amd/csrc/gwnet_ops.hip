@@ -1,6 +1,7 @@
 // Graph-WaveNet hot path for gfx950: C-ABI entry points (include/mo_hip.h) + kernels.
 // Reference semantics: /root/reference/models/graph_wavenet.py (cited per entry in mo_hip.h).
 #include "mo_gemm.hpp"
+#include "mo_rowstream.hpp"
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
@@ -118,11 +119,15 @@ static void wgrad_plan(int M, int N, long P, int& nsplit, int& kchunk) {
   if (nsplit < 1) nsplit = 1;
 }
 
+#define RSW_MAX_WG 512      // row-streaming weight gradient: 2 workgroups per CU, one slab each
 extern "C" long mo_wgrad_ws_floats(int M, int N, long P) {
   int ns, kc; wgrad_plan(M, N, P, ns, kc);
   long a = (long)ns * M * N + (long)ns * M + 64;          // slabs + fused column-sum slabs
   long b = (long)mo_cdiv(P, 512) * (M > N ? M : N) + 64;  // fallback column-sum partials
-  return a > b ? a : b;
+  long c = (long)RSW_MAX_WG * ((long)M * N + M) + 64;     // row-streaming kernel slabs
+  if ((M % 32) || (N % 32) || (M / 32) * (N / 32) > 8) c = 0;
+  a = a > b ? a : b;
+  return a > c ? a : c;
 }
 
 // out[i] (=) sum_z slab[z][i]: 32 outputs x 8 z-lanes per block, fixed summation order (deterministic)
@@ -296,9 +301,63 @@ extern "C" int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const floa
 // generic weight-gradient: slab[z][M][N] = sum_{k in chunk z} A(k,m) B(k,n), then reduce.  When `db` is
 // given, the column sums of A (the bias gradient) are produced by the same pass (fast loader) or by a
 // separate column-sum kernel over `a_plain` [P][M] (generic loader; a_plain may be null if impossible).
+// Row-streaming path (mo_rowstream.hpp): a is one unmapped [P][32*MA] segment, b is NB 32-wide segments.
+static bool rsw_ok(const MoOperand& A, const MoOperand& B, long P, int M, int N) {
+  if ((M % 32) || (N % 32)) return false;
+  const int MA = M / 32, NB = N / 32;
+  if (!(MA == 1 || MA == 2 || MA == 8) || MA * NB > 8) return false;
+  if (A.nseg != 1 || A.cols != M || A.seg[0].ld != M || A.seg[0].To != 0 || A.seg[0].scale || A.seg[0].relu) return false;
+  if (!A.seg[0].ptr || (((uintptr_t)A.seg[0].ptr) & 3)) return false;
+  if (B.nseg != NB || B.cols != N || (NB > 1 && B.segw != 32)) return false;
+  if (P * (long)M >= (1L << 32)) return false;
+  for (int j = 0; j < NB; ++j) {
+    const MoSeg& g = B.seg[j];
+    if (!g.ptr || g.ld != 32 || g.drop_thresh) return false;
+    if (g.To != B.seg[0].To || g.relu != B.seg[0].relu) return false;
+    if (g.To < 0 || g.To >= 200) return false;
+  }
+  return true;
+}
+template <int MA, int NB>
+static void rsw_launch2(const MoOperand& A, const MoOperand& B, float* slab, float* cs, long P, int post_b, int nwg,
+                        hipStream_t st) {
+  const size_t lds = (size_t)MA * NB * 16 * 64 * 2 * sizeof(float);
+  if (B.seg[0].To)
+    hipLaunchKernelGGL((rs_wgrad_kernel<MA, NB, true>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
+  else
+    hipLaunchKernelGGL((rs_wgrad_kernel<MA, NB, false>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
+}
+static void rsw_launch(int MA, int NB, const MoOperand& A, const MoOperand& B, float* slab, float* cs, long P,
+                       int post_b, int nwg, hipStream_t st) {
+#define RSW_CASE(a, b) if (MA == a && NB == b) return rsw_launch2<a, b>(A, B, slab, cs, P, post_b, nwg, st);
+  RSW_CASE(1, 1) RSW_CASE(1, 2) RSW_CASE(1, 3) RSW_CASE(1, 4) RSW_CASE(1, 5) RSW_CASE(1, 6) RSW_CASE(1, 7)
+  RSW_CASE(1, 8) RSW_CASE(2, 1) RSW_CASE(2, 2) RSW_CASE(2, 3) RSW_CASE(2, 4) RSW_CASE(8, 1)
+#undef RSW_CASE
+}
+
 static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int N, float* ws, float* dW, float* db,
-                     hipStream_t st, bool* db_done = nullptr) {
+                     hipStream_t st, bool* db_done = nullptr, int* nslab = nullptr) {
+  if (rsw_ok(A, Bo, P, M, N)) {
+    const int crows = 2 * rsw_u(M / 32, N / 32);
+    const long nchunk = (P + crows - 1) / crows;
+    long nwg = (nchunk + 3) / 4;
+    if (nwg > RSW_MAX_WG) nwg = RSW_MAX_WG;
+    float* cs = ws + nwg * (long)M * N;
+    int post_b = 0;
+    for (int j = 0; j < Bo.nseg; ++j) if (Bo.seg[j].scale) post_b |= 1;
+    if (Bo.seg[0].relu) post_b |= 2;
+    rsw_launch(M / 32, N / 32, A, Bo, ws, db ? cs : nullptr, P, post_b, (int)nwg, st);
+    if (dW) {
+      long n = (long)M * N;
+      hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(n), dim3(256), 0, st, ws, n, (int)nwg, dW, n);
+    }
+    if (db) hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(M), dim3(256), 0, st, cs, (long)M, (int)nwg, db, (long)M);
+    if (db_done) *db_done = true;
+    if (nslab) *nslab = (int)nwg;
+    return mo_launch_status();
+  }
   int nsplit, kchunk; wgrad_plan(M, N, P, nsplit, kchunk);
+  if (nslab) *nslab = nsplit;
   MoEpi E; epi_init(E, ws, N);
   E.slab_stride = (long)M * N; E.kchunk = kchunk;
   const bool fused = db && op_fast_ok(A) && op_fast_ok(Bo);
@@ -546,9 +605,9 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
     // bias gradients = column sums of dpre (64 columns), fused into the same pass: [dbf | dbg]
     float* db64 = ws2 + mo_wgrad_ws_floats(64, 32 * K, Pout) - 64;
     bool done = false;
-    rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, db64, st, &done);
+    int nsplit = 0;
+    rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, db64, st, &done, &nsplit);
     if (rc) return rc;
-    int nsplit, kchunk; wgrad_plan(64, 32 * K, Pout, nsplit, kchunk);
     hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(mo_cdiv(64 * 32 * K, 32)), dim3(256), 0, st, ws2,
                        (long)64 * 32 * K, nsplit, K, dWf, dWg);
     if (done) {
@@ -638,6 +697,27 @@ extern "C" int mo_adj_grad(const float* X, const float* dY, int N, long J, float
 // ------------------------------------------------------------------------------------------------
 extern "C" long mo_mlp_partial_floats(long P) { return ((long)mo_cdiv(P, 128) + RED_STAGE + 2) * 64; }
 
+// row-streaming mlp kernels (mo_rowstream.hpp): 16-byte aligned [P][32] tensors, byte offsets within 32 bits
+static bool rs_mlp_ok(const float* const* t, int n, long P) {
+  if (P * 128 >= (1L << 32) || n < 1 || n > 7) return false;
+  for (int s = 0; s < n; ++s) if (!t[s] || (((uintptr_t)t[s]) & 15)) return false;
+  return true;
+}
+static void rs_mlp_launch(bool fwd, int ns, const RsMlpArgs& a, hipStream_t st) {
+  const long NG = (a.P + 127) / 128;
+  long nwg = (NG + 3) / 4;
+  if (nwg > 512) nwg = 512;                       // 2 workgroups per CU
+  const bool drop = a.drop_thresh != 0;
+#define RS_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)nwg), dim3(256), 0, st, a)
+#define RS_CASE(k) if (ns == k) { \
+    if (fwd) { if (drop) RS_LAUNCH((rs_mlp_fwd_kernel<k, true>)); else RS_LAUNCH((rs_mlp_fwd_kernel<k, false>)); } \
+    else { if (drop) RS_LAUNCH((rs_mlp_bwd_kernel<k, true>)); else RS_LAUNCH((rs_mlp_bwd_kernel<k, false>)); } \
+    return; }
+  RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
+#undef RS_LAUNCH
+#undef RS_CASE
+}
+
 extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, const float* b, long G, int Tout,
                               int Tin, const float* res, const float* rscale, const float* rshift,
                               uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* h,
@@ -646,9 +726,19 @@ extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, 
   MO_CHECK_ARG(Tout > 0 && Tin >= Tout && G * Tin < (1L << 31));
   MO_CHECK_ARG((rscale == nullptr) == (rshift == nullptr));
   const long P = G * Tout;
+  for (int s = 0; s < ns; ++s) MO_CHECK_ARG(srcs[s]);
+  if (rs_mlp_ok(srcs, ns, P) && Tout < 200 && !(((uintptr_t)res) & 15)) {
+    RsMlpArgs a = {};
+    for (int s = 0; s < ns; ++s) a.src[s] = srcs[s];
+    a.out[0] = h; a.W = W; a.bias = b; a.res = res; a.rscale = rscale; a.rshift = rshift; a.partial = partial;
+    a.P = P; a.Tout = Tout; a.Tin = Tin;
+    a.drop_seed = drop_seed; a.drop_thresh = drop_thresh; a.drop_scale = drop_scale;
+    rs_mlp_launch(true, ns, a, ST(stream));
+    return mo_launch_status();
+  }
   MoOperand A; op_init(A);
   A.nseg = ns; A.segw = 32; A.rows = (int)P; A.cols = 32 * ns;
-  for (int s = 0; s < ns; ++s) { MO_CHECK_ARG(srcs[s]); seg_init(A.seg[s], srcs[s], 32); }
+  for (int s = 0; s < ns; ++s) { seg_init(A.seg[s], srcs[s], 32); }
   MoOperand Bo = op_simple(W, 32 * ns, 32, 32 * ns);   // XROWS rows = n = co, cols = k
   MoEpi E; epi_init(E, h, 32);
   E.bias = b; E.add = res; E.ldadd = 32; E.aTo = Tout; E.aTi = Tin; E.aoff = Tin - Tout;
@@ -837,7 +927,13 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
   E.out_bf = (unsigned short*)dlast_bf16; E.bf_seg = ns - 1;    // bf16 copy of the last source's gradient
   for (int s = 0; s < ns; ++s) { MO_CHECK_ARG(dsrcs[s] && srcs[s]); E.out[s] = dsrcs[s]; }
   int rc = MO_OK;
-  if (parts & 1) {
+  if ((parts & 1) && rs_mlp_ok(&dh, 1, P) && rs_mlp_ok((const float* const*)dsrcs, ns, P)) {
+    RsMlpArgs a = {};
+    a.src[0] = dh; a.W = W; a.P = P; a.out_bf = (unsigned short*)dlast_bf16;
+    for (int s = 0; s < ns; ++s) a.out[s] = dsrcs[s];
+    a.drop_seed = drop_seed; a.drop_thresh = drop_thresh; a.drop_scale = drop_scale;
+    rs_mlp_launch(false, ns, a, st);
+  } else if (parts & 1) {
     if (ns == 1)
       rc = launch<128, 32, 32, 4, 1, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, 32, 1, st);
     else

@@ -1,0 +1,430 @@
+// Row-streaming kernels for the [P][32]-channel tensors of the gwnet block (gfx950).
+//
+// The nbtc activations are tall matrices of 128-byte rows.  Every kernel here lets each wave stream rows
+// on its own -- no workgroup barriers in the main loop, tens of loads in flight per wave, 8 waves per CU --
+// which is what an HBM-bound pass needs on this chip (bytes in flight per CU / latency), and feeds the fp32
+// MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) straight from registers where the operand layout allows.
+#pragma once
+#include "mo_gemm.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients: slab[z][m][n] = sum_{p in rows of workgroup z} a(p, m) * b(p, n)
+//   a: one segment [P][32*MA] (dropout mask regenerated on load), b: NB segments [.][32] with per-segment
+//   row map / folded BatchNorm affine / ReLU.  The contraction index is the ROW, so a half-wave's 128-byte
+//   row read IS the MFMA operand (lane = column, lane>>5 = k): global_load_dword -> v_mfma, no LDS.
+//   cs[z][m] = column sums of a (the bias gradient) when cs != null.
+// ------------------------------------------------------------------------------------------------
+// row pairs in flight per wave: (MA+NB)*U loads <= 56 (the vmcnt counter is 6 bits), at most 12 pairs
+__host__ __device__ constexpr int rsw_u(int MA, int NB) {
+  return 48 / (MA + NB) > 12 ? 12 : (48 / (MA + NB) < 2 ? 2 : 48 / (MA + NB));
+}
+
+template <int MA, int NB, bool MAPPED>
+__global__ __launch_bounds__(256, 2) void rs_wgrad_kernel(MoOperand A, MoOperand B, float* __restrict__ slab,
+                                                         float* __restrict__ cs, long P, int post_b) {
+  extern __shared__ float rs_sm[];
+  constexpr int RSW_U = rsw_u(MA, NB), RSW_ROWS = 2 * RSW_U;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, half = lane >> 5;
+  const long nwaves = (long)gridDim.x * 4;
+  const long w = (long)wave * gridDim.x + blockIdx.x;      // neighbouring workgroups stream neighbouring chunks
+  const long nchunk = (P + RSW_ROWS - 1) / RSW_ROWS;
+  constexpr int LDA = 32 * MA;
+
+  f32x16 acc[MA][NB];
+#pragma unroll
+  for (int i = 0; i < MA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float csum[MA];
+#pragma unroll
+  for (int i = 0; i < MA; ++i) csum[i] = 0.f;
+
+  // per-lane constants of the b segments
+  float bsc[NB], bsh[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    bsc[j] = B.seg[j].scale ? mo_gload(B.seg[j].scale + c) : 1.f;
+    bsh[j] = B.seg[j].scale ? mo_gload(B.seg[j].shift + c) : 0.f;
+  }
+  const float* aptr = A.seg[0].ptr;
+  const uint32_t dseed = A.seg[0].drop_seed, dthresh = A.seg[0].drop_thresh;
+  const float dscale = A.seg[0].drop_scale;
+  // row map p -> (g, t): one real division per wave, then incremental (chunks advance by a fixed stride);
+  // the in-chunk offsets use a 16-bit reciprocal (exact for To < 200, checked by the host)
+  const int To = MAPPED ? B.seg[0].To : 1;
+  const unsigned inv16 = 65536u / (unsigned)To + 1u;
+  const unsigned stride = (unsigned)(nwaves * RSW_ROWS);
+  const unsigned dq = stride / (unsigned)To, dr = stride - dq * (unsigned)To;
+  unsigned g0 = 0, t0 = 0;
+  if (MAPPED) { const unsigned p0 = (unsigned)(w * RSW_ROWS); g0 = p0 / (unsigned)To; t0 = p0 - g0 * (unsigned)To; }
+
+  float ra[RSW_U][MA], rb[RSW_U][NB];
+  uint32_t aidx[RSW_U];          // element index of ra[u][0] (dropout) or ~0u when the row is past P
+  uint32_t bok[RSW_U];           // bit j: b segment j row is in range
+
+  auto issue = [&](long chunk, int u) {
+    const long p = chunk * RSW_ROWS + 2 * u + half;
+    const bool ok = p < P;
+    const long pc = ok ? p : 0;
+#pragma unroll
+    for (int i = 0; i < MA; ++i) ra[u][i] = mo_gload(aptr + pc * LDA + i * 32 + c);
+    aidx[u] = ok ? (uint32_t)(pc * LDA + c) : 0xffffffffu;
+    uint32_t okm = 0;
+    long g = pc; int t = 0;
+    if (MAPPED) {
+      const unsigned x = t0 + (unsigned)(2 * u + half);
+      const unsigned q = (x * inv16) >> 16;
+      t = (int)(x - q * (unsigned)To);
+      g = (long)(g0 + q);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      long srow = pc; bool v = ok;
+      if (MAPPED) {
+        const int tt = t + B.seg[j].off;
+        v = ok & ((unsigned)tt < (unsigned)B.seg[j].Ti);
+        srow = v ? g * B.seg[j].Ti + tt : 0;
+      }
+      rb[u][j] = mo_gload(B.seg[j].ptr + srow * 32 + c);
+      okm |= (v ? 1u : 0u) << j;
+    }
+    bok[u] = okm;
+  };
+
+  auto consume = [&](int u) {
+    float av[MA], bv[NB];
+#pragma unroll
+    for (int i = 0; i < MA; ++i) {
+      float v = ra[u][i];
+      if (dthresh) {
+        const uint32_t h = mo_hash32(dseed, aidx[u] + 32u * i);
+        v = (h >= dthresh) ? v * dscale : 0.f;
+      }
+      if (aidx[u] == 0xffffffffu) v = 0.f;
+      av[i] = v;
+      csum[i] += v;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      float v = rb[u][j];
+      if (post_b & 1) v = v * bsc[j] + bsh[j];
+      if (post_b & 2) v = fmaxf(v, 0.f);
+      if (!((bok[u] >> j) & 1)) v = 0.f;
+      bv[j] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+  };
+
+  // Straight-line steady state (no branch around the refill, or the compiler's vmcnt bookkeeping turns
+  // conservative and drains the pipeline once per chunk): the last iteration re-reads its own chunk.
+  if (w < nchunk) {
+#pragma unroll
+    for (int u = 0; u < RSW_U; ++u) issue(w, u);
+    for (long chunk = w; chunk < nchunk; chunk += nwaves) {
+      const bool more = chunk + nwaves < nchunk;
+      const long nx = more ? chunk + nwaves : chunk;
+      if (MAPPED && more) { t0 += dr; g0 += dq; if (t0 >= (unsigned)To) { t0 -= (unsigned)To; g0 += 1; } }
+#pragma unroll
+      for (int u = 0; u < RSW_U; ++u) {
+        consume(u);
+        issue(nx, u);                   // refill the slot just consumed: RSW_U-1 pairs stay in flight
+      }
+    }
+  }
+
+  // ---- workgroup reduction of the four waves' partial tiles through LDS, then one slab per workgroup
+  constexpr int TILE = MA * NB * 16 * 64;            // floats per wave
+  float* buf0 = rs_sm;                               // [TILE] x 2
+  float* buf1 = rs_sm + TILE;
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((i * NB + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * NB + j) * 16 + r) * 64 + lane];
+  };
+  if (wave == 2) put(buf0);
+  if (wave == 3) put(buf1);
+  __syncthreads();
+  if (wave == 0) add(buf0);
+  if (wave == 1) add(buf1);
+  __syncthreads();
+  if (wave == 1) put(buf0);
+  __syncthreads();
+  if (wave == 0) {
+    add(buf0);
+    float* out = slab + (long)blockIdx.x * (32 * MA) * (32 * NB);
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          out[(long)m * (32 * NB) + j * 32 + c] = acc[i][j][r];
+        }
+  }
+  if (cs) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MA; ++i) rs_sm[(wave * MA + i) * 64 + lane] = csum[i];
+    __syncthreads();
+    if (threadIdx.x < 32 * MA) {
+      const int i = threadIdx.x >> 5, cc = threadIdx.x & 31;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s += rs_sm[(q * MA + i) * 64 + cc] + rs_sm[(q * MA + i) * 64 + 32 + cc];
+      cs[(long)blockIdx.x * (32 * MA) + threadIdx.x] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row contractions over the CHANNEL axis (gcn mlp forward / data gradient): out[p][n] = sum_k x[p][k] w[k][n].
+// The MFMA wants lane = row for x, the coalesced load gives lane = column, so every 32x32 block takes one
+// trip through a wave-private LDS tile (ds_write_b128 rows in, ds_read_b128 rows out, stride 36 floats: both
+// conflict-free); no workgroup barrier after the weights are staged.  Rows are dealt to waves in runs of
+// 128 (= one BatchNorm partial row), neighbouring workgroups on neighbouring runs.
+// ------------------------------------------------------------------------------------------------
+#define RS_LDX 36
+#define RS_LDW 33
+
+struct RsMlpArgs {
+  const float* src[MO_MAX_SEG];   // fwd: the ns sources; bwd: src[0] = dh
+  float* out[MO_MAX_SEG];         // fwd: out[0] = h; bwd: the ns source gradients
+  unsigned short* out_bf;         // bwd: optional bf16 copy of out[ns-1]
+  const float* W;                 // reference mlp weight [32][32*ns]
+  const float* bias;              // fwd
+  const float* res; const float* rscale; const float* rshift;   // fwd residual (row map Tout -> Tin, offset)
+  float* partial;                 // fwd: BatchNorm partial sums [ceil(P/128)][64]
+  long P;
+  int Tout, Tin;
+  uint32_t drop_seed, drop_thresh; float drop_scale;
+};
+
+// Bounds-checked stores through a buffer descriptor (num_records = the tensor's bytes): rows past P are
+// dropped by the hardware, so the streaming loops stay branch-free (a branch around a store makes the
+// compiler's vmcnt bookkeeping conservative and drains the load pipeline).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ void rs_store_f32(__amdgpu_buffer_rsrc_t r, long elem, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)(unsigned)(elem * 4), 0, 0);
+}
+__device__ __forceinline__ void rs_store_bf16(__amdgpu_buffer_rsrc_t r, long elem, float v) {
+  __bf16 tb = (__bf16)v;
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, tb), r, (int)(unsigned)(elem * 2), 0, 0);
+}
+
+typedef unsigned rs_v4u __attribute__((ext_vector_type(4)));
+// Loads go through buffer descriptors too: one 32-bit byte offset per lane serves every source tensor of the
+// same shape (the descriptor carries the base), rows past the end read as zero.
+__device__ __forceinline__ float4 rs_load4(__amdgpu_buffer_rsrc_t r, unsigned byteoff) {
+  const rs_v4u x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteoff, 0, 0);
+  const unsigned x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];   // (bit_cast of a vector-element lvalue reads element 0)
+  return make_float4(__uint_as_float(x0), __uint_as_float(x1), __uint_as_float(x2), __uint_as_float(x3));
+}
+__device__ __forceinline__ float rs_load1(__amdgpu_buffer_rsrc_t r, unsigned byteoff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byteoff, 0, 0));
+}
+// coalesced 32-row block load of [.][32] rows: load j covers rows 8j + (lane>>3), columns 4*(lane&7)..+3;
+// lane_off = (lane>>3)*128 + (lane&7)*16
+__device__ __forceinline__ void rs_issue_block(float4 (&v)[4], __amdgpu_buffer_rsrc_t r, long row0, unsigned lane_off) {
+  const unsigned base = (unsigned)(row0 * 128) + lane_off;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = rs_load4(r, base + 1024u * j);
+}
+__device__ __forceinline__ void rs_put(float* X, const float4 (&v)[4], int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    *reinterpret_cast<float4*>(&X[(8 * j + (lane >> 3)) * RS_LDX + 4 * (lane & 7)]) = v[j];
+}
+// a[t] = x[row lane&31][k = 16*(lane>>5) + t]
+__device__ __forceinline__ void rs_get(const float* X, float (&a)[16], int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(&X[(lane & 31) * RS_LDX + 16 * (lane >> 5) + 4 * q]);
+    a[4 * q + 0] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+  }
+}
+
+template <int NS, bool DROP>
+__global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
+  __shared__ float Ws[NS * 32 * RS_LDW];
+  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  constexpr int KT = 32 * NS;
+  for (int idx = tid; idx < 32 * KT; idx += 256) {
+    const int co = idx / KT, k = idx - co * KT;
+    Ws[k * RS_LDW + co] = a.W[idx];
+  }
+  __syncthreads();
+  float* X = Xs[wave];
+  const long P = a.P;
+  const long NG = (P + 127) >> 7;
+  const long nwaves = (long)gridDim.x * 4;
+  const long w = (long)wave * gridDim.x + blockIdx.x;
+  if (w >= NG) return;
+  const float bv = a.bias[n];
+  const float asc = a.rscale ? a.rscale[n] : 1.f;
+  const float ash = a.rscale ? a.rshift[n] : 0.f;
+  const unsigned To = (unsigned)a.Tout, Ti = (unsigned)a.Tin, aoff = Ti - To;
+  const unsigned inv16 = 65536u / To + 1u;
+  const __amdgpu_buffer_rsrc_t hout = rs_rsrc(a.out[0], P * 128);
+  const __amdgpu_buffer_rsrc_t resr = rs_rsrc(a.res, (P / To) * Ti * 128);
+  __amdgpu_buffer_rsrc_t srcr[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) srcr[s] = rs_rsrc(a.src[s], P * 128);
+  const unsigned lane_off = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16);
+
+  // Ring of RS_R (block, source) tiles in flight per wave, 4 KB each; step i = 4*NS*run + NS*jb + s lives in
+  // slot i % RS_R (static: RS_R divides 4*NS) and is refilled with step i + RS_R as soon as it sits in LDS.
+  constexpr int RS_R = 4;
+  float4 ring[RS_R][4];
+  auto step_row0 = [&](long gi, int i) -> long { return gi * 128 + (i / NS) * 32; };   // i in [0, 4*NS)
+#pragma unroll
+  for (int i = 0; i < RS_R; ++i) rs_issue_block(ring[i], srcr[i % NS], step_row0(w, i), lane_off);
+
+  for (long gi = w; gi < NG; gi += nwaves) {
+    const long gnext = (gi + nwaves < NG) ? gi + nwaves : gi;     // tail: harmless re-read of the own run
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const long m0 = gi * 128 + jb * 32;
+      // residual rows of this block: (g, t) of the first row by one division, the 32 offsets by reciprocal
+      const unsigned um0 = (unsigned)(m0 < P ? m0 : 0);
+      const unsigned g0 = um0 / To, t0 = um0 - g0 * To;
+      float rres[16];       // issued first: by the epilogue they are the OLDEST loads in flight (no drain)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned ii = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const unsigned x = t0 + ii, q = (x * inv16) >> 16;
+        const unsigned rr = (g0 + q) * Ti + (x - q * To) + aoff;
+        rres[r] = rs_load1(resr, rr * 128u + 4u * n);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int i = jb * NS + s;                 // step within the run
+        const int slot = i % RS_R;
+        rs_put(X, ring[slot], lane);
+        {
+          const int in = i + RS_R;                 // the step this slot serves next
+          const long g2 = (in < 4 * NS) ? gi : gnext;
+          const int i2 = in % (4 * NS);
+          rs_issue_block(ring[slot], srcr[i2 % NS], step_row0(g2, i2), lane_off);
+        }
+        float av[16];
+        rs_get(X, av, lane);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[(s * 32 + 16 * half + t) * RS_LDW + n], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting later segments' LDS traffic
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r] + bv;
+        if (DROP) {
+          const uint32_t h = mo_hash32(a.drop_seed, (uint32_t)(m * 32 + n));
+          v = (h >= a.drop_thresh) ? v * a.drop_scale : 0.f;
+        }
+        v += rres[r] * asc + ash;
+        rs_store_f32(hout, m * 32 + n, v);
+        const float vm = (m < P) ? v : 0.f;
+        s1 += vm; s2 += vm * vm;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    a.partial[gi * 64 + lane] = half ? s2 : s1;
+  }
+}
+
+// data gradient: dsrc[s][p][:] = dm[p][:] @ W[:, 32s:32s+32], dm = dropout-masked dh
+template <int NS, bool DROP>
+__global__ __launch_bounds__(256, 2) void rs_mlp_bwd_kernel(RsMlpArgs a) {
+  __shared__ float Ws[32 * (NS * 32 + 1)];       // [k = co][n], row stride 32*NS+1
+  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  constexpr int NT = 32 * NS, LW = NT + 1;
+  for (int idx = tid; idx < 32 * NT; idx += 256) {
+    const int co = idx / NT, c = idx - co * NT;
+    Ws[co * LW + c] = a.W[idx];
+  }
+  __syncthreads();
+  float* X = Xs[wave];
+  const long P = a.P;
+  const long NG = (P + 127) >> 7;
+  const long nwaves = (long)gridDim.x * 4;
+  const long w = (long)wave * gridDim.x + blockIdx.x;
+  if (w >= NG) return;
+  const __amdgpu_buffer_rsrc_t srcr = rs_rsrc(a.src[0], P * 128);
+  const unsigned lane_off = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16);
+  float4 ring[4][4];                              // the four blocks of a run in flight
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) rs_issue_block(ring[jb], srcr, w * 128 + jb * 32, lane_off);
+  for (long gi = w; gi < NG; gi += nwaves) {
+    const long gnext = (gi + nwaves < NG) ? gi + nwaves : gi;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const long m0 = gi * 128 + jb * 32;
+      if (DROP) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t e = (uint32_t)((m0 + 8 * j + (lane >> 3)) * 32 + 4 * (lane & 7));
+          float* vp = &ring[jb][j].x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t h = mo_hash32(a.drop_seed, e + q);
+            vp[q] = (h >= a.drop_thresh) ? vp[q] * a.drop_scale : 0.f;
+          }
+        }
+      }
+      rs_put(X, ring[jb], lane);
+      rs_issue_block(ring[jb], srcr, gnext * 128 + jb * 32, lane_off);
+      float av[16];
+      rs_get(X, av, lane);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[(16 * half + t) * LW + s * 32 + n], acc, 0, 0, 0);
+        const __amdgpu_buffer_rsrc_t o = rs_rsrc(a.out[s], P * 128);
+        const __amdgpu_buffer_rsrc_t ob = rs_rsrc(a.out_bf, a.out_bf ? P * 64 : 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          rs_store_f32(o, m * 32 + n, acc[r]);
+          if (s == NS - 1) rs_store_bf16(ob, m * 32 + n, acc[r]);     // num_records 0 when absent: dropped
+        }
+        __builtin_amdgcn_sched_barrier(0);     // one accumulator tile at a time (register budget)
+      }
+    }
+  }
+}

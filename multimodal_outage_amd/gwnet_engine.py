@@ -9,6 +9,8 @@ BatchNorm of layer i is never materialised: the kernels that consume x_{i+1} = B
 folded affine (scale, shift) on load (tcn / residual), and the backward recomputes xhat from h_i.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import _lib as L
@@ -61,7 +63,8 @@ class GwnetConfig:
 # node-axis product is bracketed by HIP events on the launching stream and appended as
 # (name, algorithmic_flops, start_event, end_event).
 PROFILE = None
-SERIAL = False   # True: disable the side-stream overlap (bench.py's un-contended roofline pass)
+SERIAL = bool(int(os.environ.get('MO_SERIAL', '0')))   # True: disable the side-stream overlap (bench.py's
+                                                         # un-contended roofline pass; MO_SERIAL=1 for profiling)
 
 
 def _dense(name, N, J, *args):

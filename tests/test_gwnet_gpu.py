@@ -75,7 +75,9 @@ def test_gwnet_reference_views_vs_golden():
     loss = F.mse_loss(y, rand(102, (67, 7, 256)).cuda())
     assert abs(loss.item() - float(G['loss'])) < 1e-4
     loss.backward()
-    assert_close(x.grad, G['dx'], 1e-7, 1e-3, 'dx')
+    # input gradient: fp32 summation-order noise of the reference itself is ~3e-3 of the tensor scale (fp64 yardstick,
+    # tests/helpers.check_grads_vs_f64), so the absolute term is stated relative to max|dx| (6.3e-5 here)
+    assert_close(x.grad, G['dx'], 5e-3 * float(np.abs(G['dx']).max()), 1e-3, 'dx')
     check_grads({k: v.grad for k, v in m.named_parameters()}, G, atol=2e-6, rtol=1e-3)
     sd = m.state_dict()
     for k in G.files:
