@@ -119,7 +119,7 @@ static void wgrad_plan(int M, int N, long P, int& nsplit, int& kchunk) {
   if (nsplit < 1) nsplit = 1;
 }
 
-#define RSW_MAX_WG 512      // row-streaming weight gradient: 2 workgroups per CU, one slab each
+#define RSW_MAX_WG 768      // row-streaming weight gradient: up to 3 workgroups per CU, one slab each
 extern "C" long mo_wgrad_ws_floats(int M, int N, long P) {
   int ns, kc; wgrad_plan(M, N, P, ns, kc);
   long a = (long)ns * M * N + (long)ns * M + 64;          // slabs + fused column-sum slabs
@@ -341,7 +341,8 @@ static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int
     const int crows = 2 * rsw_u(M / 32, N / 32);
     const long nchunk = (P + crows - 1) / crows;
     long nwg = (nchunk + 3) / 4;
-    if (nwg > RSW_MAX_WG) nwg = RSW_MAX_WG;
+    const long cap = 512;                                      // 2 workgroups per CU (register budget)
+    if (nwg > cap) nwg = cap;
     float* cs = ws + nwg * (long)M * N;
     int post_b = 0;
     for (int j = 0; j < Bo.nseg; ++j) if (Bo.seg[j].scale) post_b |= 1;
@@ -547,6 +548,25 @@ static void tcn_operands(const float* h_prev, const float* scale, const float* s
   for (int t = 0; t < K; ++t) seg_init(Bo.seg[t], Wp + (long)t * 64 * 32, 32);
 }
 
+// row-streaming TCN kernels (mo_rowstream.hpp)
+static bool rs_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static bool rs_tcn_ok(int K, long G, int Tin, int Tout) {
+  return K >= 1 && K <= 3 && Tin < 200 && Tout >= 1 && G * (long)Tin * 256 < 0xFFFFF000L;
+}
+static void rs_tcn_launch(int which, int K, const RsTcnArgs& a, long rows, hipStream_t st) {
+  const long NG = (rows + 127) / 128;
+  long nwg = (NG + 3) / 4;
+  const long cap = (K <= 2 && which == 0) ? 768 : 512;      // workgroups per CU the kernel's registers allow
+  if (nwg > cap) nwg = cap;
+#define RS_LAUNCH(KER) hipLaunchKernelGGL(KER, dim3((unsigned)nwg), dim3(256), 0, st, a)
+#define RS_CASE(k) if (K == k) { \
+    if (which == 0) RS_LAUNCH((rs_tcn_kernel<k, 0>)); else if (which == 1) RS_LAUNCH((rs_tcn_kernel<k, 1>)); \
+    else RS_LAUNCH((rs_tcn_du_kernel<k>)); return; }
+  RS_CASE(1) RS_CASE(2) RS_CASE(3)
+#undef RS_CASE
+#undef RS_LAUNCH
+}
+
 extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                           const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
                           void* g_bf16, void* stream) {
@@ -554,6 +574,13 @@ extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* 
   MO_CHECK_ARG(h_prev && Wp && bf && bg && g_out && K >= 1 && K <= MO_MAX_SEG && G > 0 && Tout > 0);
   MO_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   MO_CHECK_ARG(G * Tin < (1L << 31));
+  if (rs_tcn_ok(K, G, Tin, Tout) && rs_al16(h_prev) && rs_al16(g_out) && rs_al16(scale) && rs_al16(shift)) {
+    RsTcnArgs a = {};
+    a.h_prev = h_prev; a.scale = scale; a.shift = shift; a.Wp = Wp; a.bf = bf; a.bg = bg;
+    a.out = g_out; a.out_bf = (unsigned short*)g_bf16; a.G = G; a.Tin = Tin; a.Tout = Tout; a.dil = dil;
+    rs_tcn_launch(0, K, a, G * Tout, ST(stream));
+    return mo_launch_status();
+  }
   MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
   MoEpi E; epi_init(E, g_out, 32);
   E.bias = bf; E.bias2 = bg; E.out_bf = (unsigned short*)g_bf16;
@@ -570,8 +597,20 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
   hipStream_t st = ST(stream);
   const long Pout = G * Tout, Pin = G * Tin;
   int rc = MO_OK;
+  const bool rs = rs_tcn_ok(K, G, Tin, Tout) && rs_al16(h_prev) && rs_al16(dg) && rs_al16(dpre_ws) &&
+                  rs_al16(scale) && rs_al16(shift) && rs_al16(du) && rs_al16(dres);
+  if (rs && (parts & 1)) {
+    RsTcnArgs a = {};
+    a.h_prev = h_prev; a.scale = scale; a.shift = shift; a.Wp = Wp; a.bf = bf; a.bg = bg;
+    a.dg = dg; a.out = dpre_ws; a.G = G; a.Tin = Tin; a.Tout = Tout; a.dil = dil;
+    rs_tcn_launch(1, K, a, Pout, st);
+    if (du) {
+      a.dpre = dpre_ws; a.dres = dres; a.du = du;
+      rs_tcn_launch(2, K, a, Pin, st);
+    }
+  }
   // 1) recompute pre-activations, dpre[p][0:32] = d/d(filter pre-act), [32:64] = d/d(gate pre-act)
-  if (parts & 1) {
+  if (!rs && (parts & 1)) {
     MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
     MoEpi E; epi_init(E, dpre_ws, 64);
     E.bias = bf; E.bias2 = bg; E.aux = dg; E.ldaux = 32;
@@ -579,7 +618,7 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
     if (rc) return rc;
   }
   // 2) data gradient: du[(g,t)][ci] = sum_tau sum_co' dpre[(g,t-tau*d)][co'] Wp[tau][co'][ci]  (+ residual)
-  if ((parts & 1) && du) {
+  if (!rs && (parts & 1) && du) {
     MoOperand A2; op_init(A2);
     A2.nseg = K; A2.segw = 64; A2.rows = (int)Pin; A2.cols = 64 * K;
     for (int t = 0; t < K; ++t) {

@@ -428,3 +428,225 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_bwd_kernel(RsMlpArgs a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Gated TCN (graph_wavenet.py:222-226) on the row-streaming scheme: the K taps of a 32-row output block are
+// K row-mapped 32x32 tiles of h_prev (BatchNorm affine folded in front of the LDS trip), contracted with the
+// packed weights into a filter and a gate tile; MODE 0 writes g = tanh(f) * sigmoid(g) (+ bf16 copy), MODE 1
+// the pre-activation gradients dpre[p][0:32 | 32:64] from dg.  Unmapped / out-of-range rows are fetched with
+// an out-of-range buffer offset and read as zero: no branches in the stream.
+// ------------------------------------------------------------------------------------------------
+#define RS_OOB 0xFFFFF000u
+
+struct RsTcnArgs {
+  const float* h_prev; const float* scale; const float* shift;   // [G*Tin][32], folded BatchNorm (may be null)
+  const float* Wp;                  // packed [tau][co' (64)][ci (32)]
+  const float* bf; const float* bg;
+  const float* dg;                  // MODE 1: [G*Tout][32]
+  float* out;                       // MODE 0: g [G*Tout][32]; MODE 1: dpre [G*Tout][64]
+  unsigned short* out_bf;           // MODE 0: optional bf16 copy
+  const float* dpre; const float* dres; float* du;   // data-gradient kernel
+  long G; int Tin, Tout, dil;
+};
+
+// byte offsets of the four 16-byte loads of a row-mapped 32x32 tile: output rows m0 + 8j + (lane>>3) of a
+// [.][To] row space map to source rows (g, t + shift) of a [.][Ti] space (RS_OOB when outside)
+__device__ __forceinline__ void rs_tile_offsets(unsigned (&off)[4], long m0, long P, unsigned To, unsigned Ti,
+                                                unsigned inv16, int shift, unsigned rowbytes, unsigned colbytes,
+                                                int lane) {
+  const unsigned um0 = (unsigned)(m0 < P ? m0 : 0);
+  const unsigned g0 = um0 / To, t0 = um0 - g0 * To;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned o = 8 * j + (lane >> 3);
+    const unsigned x = t0 + o, q = (x * inv16) >> 16;
+    const int tt = (int)(x - q * To) + shift;
+    const bool ok = ((unsigned)tt < Ti) & (m0 + o < P);
+    off[j] = ok ? ((g0 + q) * Ti + (unsigned)tt) * rowbytes + colbytes : RS_OOB;
+  }
+}
+__device__ __forceinline__ void rs_issue_tile(float4 (&v)[4], __amdgpu_buffer_rsrc_t r, const unsigned (&off)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = rs_load4(r, off[j]);
+}
+
+template <int K, int MODE>
+__global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_kernel(RsTcnArgs a) {
+  constexpr int LW = 65;
+  __shared__ float Ws[K * 32 * LW];                 // [tau*32 + ci][co']
+  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  for (int idx = tid; idx < K * 64 * 32; idx += 256) {
+    const int tau = idx / 2048, rem = idx - tau * 2048, cop = rem >> 5, ci = rem & 31;
+    Ws[(tau * 32 + ci) * LW + cop] = a.Wp[idx];
+  }
+  __syncthreads();
+  float* X = Xs[wave];
+  const unsigned To = (unsigned)a.Tout, Ti = (unsigned)a.Tin;
+  const long P = a.G * To;
+  const long NG = (P + 127) >> 7;
+  const long nwaves = (long)gridDim.x * 4;
+  const long w = (long)wave * gridDim.x + blockIdx.x;
+  if (w >= NG) return;
+  const unsigned inv16 = 65536u / To + 1u;
+  const __amdgpu_buffer_rsrc_t hr = rs_rsrc(a.h_prev, a.G * Ti * 128);
+  const __amdgpu_buffer_rsrc_t outr = rs_rsrc(a.out, P * (MODE == 0 ? 128 : 256));
+  const __amdgpu_buffer_rsrc_t bfr = rs_rsrc(a.out_bf, (MODE == 0 && a.out_bf) ? P * 64 : 0);
+  const __amdgpu_buffer_rsrc_t dgr = rs_rsrc(a.dg, MODE == 1 ? P * 128 : 0);
+  const unsigned colb = (unsigned)((lane & 7) * 16);
+  // folded BatchNorm affine of the lane's four columns
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.scale) {
+    sc = *reinterpret_cast<const float4*>(a.scale + 4 * (lane & 7));
+    sh = *reinterpret_cast<const float4*>(a.shift + 4 * (lane & 7));
+  }
+  const float bfv = a.bf[n], bgv = a.bg[n];
+
+  constexpr int RS_R = 4, SPR = 4 * K;              // ring slots; steps per 128-row run
+  float4 ring[RS_R][4];
+  auto issue_step = [&](float4 (&dst)[4], long gi, int i) {   // step i of run gi: block i / K, tap i % K
+    unsigned off[4];
+    rs_tile_offsets(off, gi * 128 + (i / K) * 32, P, To, Ti, inv16, (i % K) * a.dil, 128u, colb, lane);
+    rs_issue_tile(dst, hr, off);
+  };
+#pragma unroll
+  for (int i = 0; i < RS_R; ++i) issue_step(ring[i], w, i);
+
+  for (long gi = w; gi < NG; gi += nwaves) {
+    const long gnext = (gi + nwaves < NG) ? gi + nwaves : gi;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const long m0 = gi * 128 + jb * 32;
+      float dgv[16];
+      if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          dgv[r] = rs_load1(dgr, (unsigned)(m * 128 + 4 * n));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x16 accf, accg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accf[r] = 0.f; accg[r] = 0.f; }
+#pragma unroll
+      for (int tau = 0; tau < K; ++tau) {
+        const int i = jb * K + tau, slot = i % RS_R;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4& v = ring[slot][j];
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+        rs_put(X, ring[slot], lane);
+        {
+          const int in = i + RS_R;
+          issue_step(ring[slot], in < SPR ? gi : gnext, in % SPR);
+        }
+        float av[16];
+        rs_get(X, av, lane);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float* wrow = &Ws[(tau * 32 + 16 * half + t) * LW];
+          accf = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wrow[n], accf, 0, 0, 0);
+          accg = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wrow[32 + n], accg, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float f = mo_tanh(accf[r] + bfv);
+        const float g = mo_sigmoid(accg[r] + bgv);
+        if (MODE == 0) {
+          rs_store_f32(outr, m * 32 + n, f * g);
+          rs_store_bf16(bfr, m * 32 + n, f * g);
+        } else {
+          rs_store_f32(outr, m * 64 + n, dgv[r] * g * (1.f - f * f));
+          rs_store_f32(outr, m * 64 + 32 + n, dgv[r] * f * g * (1.f - g));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// data gradient of the gated TCN: du[(g,t)][ci] = sum_tau dpre[(g, t - tau*d)][0:64] @ Wp[tau] (+ dres[(g, t - (Tin-Tout))])
+template <int K>
+__global__ __launch_bounds__(256, 2) void rs_tcn_du_kernel(RsTcnArgs a) {
+  __shared__ float Ws[K * 64 * RS_LDW];             // [tau*64 + co'][ci]
+  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  for (int idx = tid; idx < K * 64 * 32; idx += 256) Ws[(idx >> 5) * RS_LDW + (idx & 31)] = a.Wp[idx];
+  __syncthreads();
+  float* X = Xs[wave];
+  const unsigned To = (unsigned)a.Tout, Ti = (unsigned)a.Tin;
+  const long P = a.G * Ti;                          // rows of du
+  const long NG = (P + 127) >> 7;
+  const long nwaves = (long)gridDim.x * 4;
+  const long w = (long)wave * gridDim.x + blockIdx.x;
+  if (w >= NG) return;
+  const unsigned inv16 = 65536u / Ti + 1u;
+  const __amdgpu_buffer_rsrc_t dpr = rs_rsrc(a.dpre, a.G * To * 256);
+  const __amdgpu_buffer_rsrc_t dur = rs_rsrc(a.du, P * 128);
+  const __amdgpu_buffer_rsrc_t drr = rs_rsrc(a.dres, a.dres ? a.G * To * 128 : 0);
+  const unsigned colb = (unsigned)((lane & 7) * 16);
+
+  constexpr int RS_R = 4, SPB = 2 * K, SPR = 4 * SPB;   // steps: (tap, half) tiles of [32 rows][32 of 64 columns]
+  float4 ring[RS_R][4];
+  auto issue_step = [&](float4 (&dst)[4], long gi, int i) {
+    const int st = i % SPB, tau = st >> 1, hh = st & 1;
+    unsigned off[4];
+    rs_tile_offsets(off, gi * 128 + (i / SPB) * 32, P, Ti, To, inv16, -tau * a.dil, 256u, colb + 128u * hh, lane);
+    rs_issue_tile(dst, dpr, off);
+  };
+#pragma unroll
+  for (int i = 0; i < RS_R; ++i) issue_step(ring[i], w, i);
+
+  for (long gi = w; gi < NG; gi += nwaves) {
+    const long gnext = (gi + nwaves < NG) ? gi + nwaves : gi;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const long m0 = gi * 128 + jb * 32;
+      // residual rows (g, t - (Tin - Tout)) of the [G*Tout][32] gradient, in the accumulator layout
+      const unsigned um0 = (unsigned)(m0 < P ? m0 : 0);
+      const unsigned g0 = um0 / Ti, t0 = um0 - g0 * Ti;
+      float rres[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned ii = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const unsigned x = t0 + ii, q = (x * inv16) >> 16;
+        const int tt = (int)(x - q * Ti) - (int)(Ti - To);
+        const bool ok = (tt >= 0) & (m0 + ii < P);
+        rres[r] = rs_load1(drr, ok ? ((g0 + q) * To + (unsigned)tt) * 128u + 4u * n : RS_OOB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < SPB; ++st) {
+        const int i = jb * SPB + st, slot = i % RS_R;
+        rs_put(X, ring[slot], lane);
+        {
+          const int in = i + RS_R;
+          issue_step(ring[slot], in < SPR ? gi : gnext, in % SPR);
+        }
+        float av[16];
+        rs_get(X, av, lane);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[((st >> 1) * 64 + (st & 1) * 32 + 16 * half + t) * RS_LDW + n],
+                                                     acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        rs_store_f32(dur, m * 32 + n, acc[r] + rres[r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}

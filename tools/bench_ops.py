@@ -79,6 +79,13 @@ if want('spmm'):
     ms = timeit(lambda: L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), N, L.ptr(X), L.ptr(Y), J,
                                1, st))
     report('spmm_csr beta=1', ms, 3 * row)
+    rpI, ciI, vaI = csr_from_dense(np.eye(N, dtype=np.float32))
+    csrI = [torch.from_numpy(x).to(dev) for x in (rpI, ciI, vaI)]
+    ms = timeit(lambda: L.call('mo_spmm_csr', L.ptr(csrI[0]), L.ptr(csrI[1]), L.ptr(csrI[2]), N, L.ptr(X), L.ptr(Y), J,
+                               0, st))
+    report('spmm_csr identity (pure copy)', ms, 2 * row)
+    ms = timeit(lambda: Y.copy_(X))
+    report('torch copy_', ms, 2 * row)
 
 if want('mlp_fwd'):
     ms = timeit(lambda: L.call('mo_gcn_mlp_fwd', L.ptr_array(srcs), ns, L.ptr(W), L.ptr(b), G, Tout, Tin,
