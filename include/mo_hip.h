@@ -43,6 +43,12 @@ int mo_nbtc_to_nchw(const float* y, float* x, int B, int C, int N, int T, void* 
 int mo_conv1x1_fwd(const float* in, int Ci, int To, int Ti, int off, int in_relu,
                    const float* W, const float* b, int Co, float* out, long P_out, int out_relu,
                    int beta, void* stream);
+/* All skip convs of the stack in one pass (graph_wavenet.py:230-236: skip = s_i + skip[..., -T_i:], so only the
+ * last Tf steps of every s_i reach the head):  skip[(grp,t)][co] (+)= bias[co] + sum_i sum_ci
+ * g_i[(grp, t + Tout[i] - Tf)][ci] * W_i[co][ci],  t in [0,Tf).  nl <= 8 layers per call (chain more with beta);
+ * bias = the sum of the layers' biases (may be null).  g_i [G*Tout[i]][32], W_i (Cs,32,1,1), skip [G*Tf][Cs]. */
+int mo_skip_fwd(const float* const* g, const int* Tout, const float* const* W, int nl, const float* bias,
+                int Cs, long G, int Tf, float* skip, int beta, void* stream);
 /* din[omap(p)][ci] (+)= sum_co dout[p][co]*W[co][ci], optionally masked by (mask[p'][ci] > 0) where p'
  * indexes the rows of din (ReLU backward); output rows mapped as above (rows without image skipped). */
 int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const float* W, int Ci, float* din,

@@ -285,6 +285,30 @@ extern "C" int mo_conv1x1_fwd(const float* in, int Ci, int To, int Ti, int off, 
   return launch<128, 128, 16, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P_out, Co, 1, ST(stream));
 }
 
+// Every layer's skip conv in one contraction over the concatenated channel axis (K = 32 * nl): the skip tensor
+// is written once instead of being read-modified-written by each layer.
+extern "C" int mo_skip_fwd(const float* const* g, const int* Tout, const float* const* W, int nl, const float* bias,
+                           int Cs, long G, int Tf, float* skip, int beta, void* stream) {
+  MO_CHECK_ARG(g && Tout && W && skip && nl >= 1 && nl <= MO_MAX_SEG && Cs > 0 && G > 0 && Tf > 0);
+  const long P = G * Tf;
+  MO_CHECK_ARG(P < (1L << 31));
+  MoOperand A; op_init(A);
+  A.nseg = nl; A.segw = 32; A.rows = (int)P; A.cols = 32 * nl;
+  MoOperand Bo; op_init(Bo);
+  Bo.nseg = nl; Bo.segw = 32; Bo.rows = Cs; Bo.cols = 32 * nl;     // XROWS: rows = n = co, cols = k = (layer, ci)
+  for (int i = 0; i < nl; ++i) {
+    MO_CHECK_ARG(g[i] && W[i] && Tout[i] >= Tf);
+    seg_init(A.seg[i], g[i], 32);
+    A.seg[i].To = Tf; A.seg[i].Ti = Tout[i]; A.seg[i].off = Tout[i] - Tf;
+    seg_init(Bo.seg[i], W[i], 32);
+  }
+  MoEpi E; epi_init(E, skip, Cs);
+  E.bias = bias; E.beta = beta;
+  if (Cs <= 32)
+    return launch<128, 32, 32, 4, 1, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Cs, 1, ST(stream));
+  return launch<128, 128, 16, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Cs, 1, ST(stream));
+}
+
 extern "C" int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const float* W, int Ci, float* din,
                                    int oTo, int oTi, int ooff, const float* mask, int beta, void* stream) {
   MO_CHECK_ARG(dout && W && din && Ci > 0 && Co > 0 && P > 0 && P < (1L << 31));

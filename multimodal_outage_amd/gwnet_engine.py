@@ -235,9 +235,6 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_tcn_fwd', L.ptr(h), L.ptr(scale), L.ptr(shift), L.ptr(Wp),
                    L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, d, G, Tin,
                    L.ptr(g), L.ptr(g_bf), st)
-            L.call('mo_conv1x1_fwd', L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
-                   L.ptr(p[f'skip_convs.{i}.weight']), L.ptr(p[f'skip_convs.{i}.bias']), cfg.Cs,
-                   L.ptr(skip), G * Tf, 0, 1 if i > 0 else 0, st)
             srcs = [g]
             bf_saved = None
             if cfg.gcn:
@@ -289,6 +286,16 @@ class GwnetFunction(torch.autograd.Function):
                                stats=stats, Tin=Tin, Tout=Tout, seed=seed, thresh=lt, dscale=ls))
             h, scale, shift, Tin = hn, stats[0], stats[1], Tout
 
+        # skip path (graph_wavenet.py:230-236): only the last Tf steps of every layer's skip conv reach the head,
+        # so all of them are ONE contraction over the concatenated channels; skip is written once
+        import ctypes as _C
+        for c0 in range(0, cfg.L, 8):
+            ids = list(range(c0, min(cfg.L, c0 + 8)))
+            bsum = torch.stack([p[f'skip_convs.{i}.bias'] for i in ids]).sum(0)
+            touts = (_C.c_int * len(ids))(*[layers[i]['Tout'] for i in ids])
+            L.call('mo_skip_fwd', L.ptr_array([layers[i]['g'] for i in ids]), touts,
+                   L.ptr_array([p[f'skip_convs.{i}.weight'] for i in ids]), len(ids), L.ptr(bsum), cfg.Cs, G, Tf,
+                   L.ptr(skip), 1 if c0 > 0 else 0, st)
         P_f = G * Tf
         r1 = _e(P_f, cfg.Ce, dev)
         L.call('mo_conv1x1_fwd', L.ptr(skip), cfg.Cs, 0, 0, 0, 1, L.ptr(p['end_conv_1.weight']),
