@@ -85,7 +85,8 @@ int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, cons
  * Y[w][:] (+)= sum_e vals[e] * X[colidx[e]][:],  e in [rowptr[w], rowptr[w+1]);  rows of J floats.
  * forward uses the CSR of A^T (out[w] = sum_v A[v,w] x[v]); backward the CSR of A. */
 int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const float* vals, int n_rows,
-                const float* X, float* Y, long J, int beta, void* stream);
+                const void* X, void* Y, long J, int beta, int x_bf16, int y_bf16 /* storage type of X / Y rows:
+                0 fp32, 1 bf16 (fp32 accumulation either way) */, void* stream);
 /* dense support: Y[N][J] (+)= A_km^T @ X with A_km (N,N) row-major indexed [k][m]
  * (forward: A_km = adp; backward-data: A_km = adp^T). */
 int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, long J, int beta, void* stream);
@@ -95,7 +96,8 @@ int mo_adj_grad(const float* X, const float* dY, int N, long J, float* dA, int b
 /* bf16-operand / fp32-accumulate variants of the dense products (the throughput mode of BASELINE
  * config 2): D[M][N] (+)= A[M][K] * B, A bf16 k-contiguous, B bf16 either [K][N] (b_krows=1: the nbtc
  * activation matrix as stored; fetched with ds_read_b64_tr_b16) or [N][K] (b_krows=0).  lda, ldb, K
- * (and N when b_krows) must be multiples of 8.  mo_f32_to_bf16: round-to-nearest-even, n % 8 == 0. */
+ * (and N when b_krows) must be multiples of 8.  D may be NULL when D_bf16 is given (bf16-only result; beta then
+ * accumulates onto the stored bf16 values).  mo_f32_to_bf16: round-to-nearest-even, n % 8 == 0. */
 int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
                  int N, int K, int beta, void* D_bf16 /* optional bf16 copy of D, may be NULL */, void* stream);
 int mo_f32_to_bf16(const float* x, void* y, long n, void* stream);
@@ -114,7 +116,8 @@ long mo_mlp_partial_floats(long P);
 int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, const float* b, long G, int Tout,
                    int Tin, const float* res, const float* rscale, const float* rshift,
                    uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* h,
-                   float* partial, void* stream);
+                   float* partial, int src_bf16_mask /* 0, or every bit but bit 0: srcs[1..] are stored as bf16 */,
+                   void* stream);
 /* BatchNorm2d finalize (training: batch stats + running-stat update, momentum 0.1 semantics of
  * nn.BatchNorm2d; eval: running stats).  Outputs scale/shift (the folded affine), mean, rstd. */
 int mo_bn_finalize(const float* partial, long nblk, long count, const float* gamma, const float* beta,
@@ -129,7 +132,9 @@ int mo_bn_bwd(const float* dy, const float* h, long P, const float* gamma, const
 int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrcs, int ns,
                    const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
                    float* dW, float* db, float* ws, void* dlast_bf16 /* optional bf16 copy of dsrcs[ns-1] */,
-                   int parts /* 1: data gradients, 2: weight/bias gradients, 3: both */, void* stream);
+                   int parts /* 1: data gradients, 2: weight/bias gradients, 3: both */,
+                   int src_bf16_mask /* as in mo_gcn_mlp_fwd */, int dsrc_bf16_mask /* same form: dsrcs[1..] are
+                   bf16 tensors */, void* stream);
 
 /* ---- loss + metrics (lit.py:33-38): sums[0..3] = {sum d^2, sum |d|, sum |d|/max(|y|,1.17e-6), n};
  *      grad (optional) = 2*d/n.  ws: mo_metrics_ws_floats(n). --------------------------------------- */

@@ -32,7 +32,7 @@ SIGNATURES = {
     'mo_tcn_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, vp]),
     'mo_tcn_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, vp,
                          vp, vp, i32, vp]),
-    'mo_spmm_csr': (i32, [vp, vp, vp, i32, vp, vp, i64, i32, vp]),
+    'mo_spmm_csr': (i32, [vp, vp, vp, i32, vp, vp, i64, i32, i32, i32, vp]),
     'mo_adj_gemm': (i32, [vp, i32, vp, vp, i64, i32, vp]),
     'mo_adj_grad': (i32, [vp, vp, i32, i64, vp, i32, vp]),
     'mo_gemm_bf16': (i32, [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
@@ -40,10 +40,10 @@ SIGNATURES = {
     'mo_gemm_bf16_256': (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     'mo_f32_to_bf16_padded': (i32, [vp, i32, i32, vp, i32, vp]),
     'mo_mlp_partial_floats': (i64, [i64]),
-    'mo_gcn_mlp_fwd': (i32, [vp, i32, vp, vp, i64, i32, i32, vp, vp, vp, u32, u32, f32, vp, vp, vp]),
+    'mo_gcn_mlp_fwd': (i32, [vp, i32, vp, vp, i64, i32, i32, vp, vp, vp, u32, u32, f32, vp, vp, i32, vp]),
     'mo_bn_finalize': (i32, [vp, i64, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     'mo_bn_bwd': (i32, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
-    'mo_gcn_mlp_bwd': (i32, [vp, vp, vp, i32, vp, i64, u32, u32, f32, vp, vp, vp, vp, i32, vp]),
+    'mo_gcn_mlp_bwd': (i32, [vp, vp, vp, i32, vp, i64, u32, u32, f32, vp, vp, vp, vp, i32, i32, i32, vp]),
     'mo_metrics_ws_floats': (i64, [i64]),
     'mo_mse_metrics': (i32, [vp, vp, i64, vp, vp, vp, vp]),
     'mo_date2vec_encode': (i32, [vp, i64, vp, vp, i32, vp, vp, i32, vp, vp]),

@@ -147,10 +147,14 @@ gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (m >= M) continue;
-        float* o = D + (long)m * ldd + n;
         float v = acc[i][j][r];
-        if (beta) v += *o;
-        *o = v;
+        if (D) {
+          float* o = D + (long)m * ldd + n;
+          if (beta) v += *o;
+          *o = v;
+        } else if (beta) {      // bf16-only output: accumulate onto the stored bf16 value
+          v += __uint_as_float(((unsigned)Dbf[(long)m * ldd + n]) << 16);
+        }
         if (Dbf) { __bf16 t = (__bf16)v; Dbf[(long)m * ldd + n] = __builtin_bit_cast(unsigned short, t); }
       }
     }
@@ -158,7 +162,7 @@ gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__
 
 extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
                             int N, int K, int beta, void* D_bf16, void* stream) {
-  MO_CHECK_ARG(A && B && D && M > 0 && N > 0 && K > 0);
+  MO_CHECK_ARG(A && B && (D || D_bf16) && M > 0 && N > 0 && K > 0);
   // 16-byte chunk loads: leading dimensions and the contiguous extents must be multiples of 8 elements
   MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (K % 8) == 0 && (!b_krows || (N % 8) == 0));
   MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
@@ -356,10 +360,14 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (m >= M) continue;
-        float* o = D + (long)m * ldd + n;
         float v = acc[i][j][r];
-        if (beta) v += *o;
-        *o = v;
+        if (D) {
+          float* o = D + (long)m * ldd + n;
+          if (beta) v += *o;
+          *o = v;
+        } else if (beta) {      // bf16-only output: accumulate onto the stored bf16 value
+          v += __uint_as_float(((unsigned)Dbf[(long)m * ldd + n]) << 16);
+        }
         if (Dbf) { __bf16 t = (__bf16)v; Dbf[(long)m * ldd + n] = __builtin_bit_cast(unsigned short, t); }
       }
     }
@@ -368,7 +376,7 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
 // a_kpad: number of readable columns of A (>= K rounded up to 32, zero beyond K)
 extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
                                 int ldd, int M, int N, int K, int beta, void* D_bf16, void* stream) {
-  MO_CHECK_ARG(A && B && D && M > 0 && N >= 8 && K > 0);
+  MO_CHECK_ARG(A && B && (D || D_bf16) && M > 0 && N >= 8 && K > 0);
   MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (!b_krows || (N % 8) == 0));
   MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
   const int kpad = (K + 31) / 32 * 32;

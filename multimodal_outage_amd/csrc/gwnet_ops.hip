@@ -13,7 +13,7 @@
 static void seg_init(MoSeg& s, const float* ptr, int ld) {
   s.ptr = ptr; s.scale = nullptr; s.shift = nullptr; s.ld = ld;
   s.To = 0; s.Ti = 0; s.off = 0; s.relu = 0; s.drop_seed = 0; s.drop_thresh = 0; s.drop_scale = 1.f;
-  s.pad_ = 0;
+  s.bf16 = 0;
 }
 static void op_init(MoOperand& o) {
   for (int i = 0; i < MO_MAX_SEG; ++i) seg_init(o.seg[i], nullptr, 0);
@@ -96,6 +96,10 @@ static int launch(const MoOperand& A, const MoOperand& B, const MoEpi& E, long M
                        block, 0, st, A, B, E, G);
   }
   return mo_launch_status();
+}
+static bool op_has_bf16(const MoOperand& o) {
+  for (int q = 0; q < o.nseg && q < MO_MAX_SEG; ++q) if (o.seg[q].bf16) return true;
+  return false;
 }
 
 extern "C" int mo_set_option(const char* name, int value) {
@@ -339,6 +343,9 @@ static bool rsw_ok(const MoOperand& A, const MoOperand& B, long P, int M, int N)
     if (!g.ptr || g.ld != 32 || g.drop_thresh) return false;
     if (g.To != B.seg[0].To || g.relu != B.seg[0].relu) return false;
     if (g.To < 0 || g.To >= 200) return false;
+    // bf16 storage: all of segments 1.. or none, segment 0 fp32, identity row map
+    if (g.bf16 != ((j > 0) ? B.seg[NB > 1 ? 1 : 0].bf16 : 0)) return false;
+    if (g.bf16 && g.To) return false;
   }
   return true;
 }
@@ -346,7 +353,9 @@ template <int MA, int NB>
 static void rsw_launch2(const MoOperand& A, const MoOperand& B, float* slab, float* cs, long P, int post_b, int nwg,
                         hipStream_t st) {
   const size_t lds = (size_t)MA * NB * 16 * 64 * 2 * sizeof(float);
-  if (B.seg[0].To)
+  if (NB > 1 && B.seg[1].bf16)       // bf16-stored sources 1.. (the gcn mlp of the throughput mode; unmapped)
+    hipLaunchKernelGGL((rs_wgrad_kernel<MA, NB, false, true>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
+  else if (B.seg[0].To)
     hipLaunchKernelGGL((rs_wgrad_kernel<MA, NB, true>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
   else
     hipLaunchKernelGGL((rs_wgrad_kernel<MA, NB, false>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
@@ -724,16 +733,96 @@ __global__ void spmm_csr_kernel(const int* __restrict__ rowptr, const int* __res
   }
   Y[(long)row * J4 + j] = acc;
 }
+
+// bf16-stored rows on either side (the throughput mode keeps the diffusion intermediates as bf16 tensors):
+// eight columns per lane, so a bf16 row piece is one 16-byte load/store; fp32 accumulation.
+struct Spmm8 { float v[8]; };
+__device__ __forceinline__ Spmm8 spmm_ld8(const void* base, long idx8, bool bf) {
+  Spmm8 r;
+  if (bf) {
+    const uint4 u = reinterpret_cast<const uint4*>(base)[idx8];
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+  } else {
+    const float4 a = reinterpret_cast<const float4*>(base)[2 * idx8], c = reinterpret_cast<const float4*>(base)[2 * idx8 + 1];
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = c.x; r.v[5] = c.y; r.v[6] = c.z; r.v[7] = c.w;
+  }
+  return r;
+}
+__device__ __forceinline__ unsigned spmm_pack2(float a, float b) {
+  __bf16 ta = (__bf16)a, tb = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ta) | ((unsigned)__builtin_bit_cast(unsigned short, tb) << 16);
+}
+template <bool XBF, bool YBF>
+__global__ void spmm_csr8_kernel(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                 const float* __restrict__ vals, const void* __restrict__ X, void* __restrict__ Y,
+                                 long J8, int n_rows, int n_panels, int beta) {
+  const long b = blockIdx.x;
+  const int xcd = (int)(b & 7);
+  const long i = b >> 3;
+  const int panel = (int)(i / n_rows) * 8 + xcd;
+  const int row = (int)(i % n_rows);
+  if (panel >= n_panels) return;
+  const long j = (long)panel * SPMM_PANEL + threadIdx.x;
+  if (j >= J8) return;
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  Spmm8 acc;
+  if (beta) acc = spmm_ld8(Y, (long)row * J8 + j, YBF);
+  else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc.v[c] = 0.f;
+  }
+  for (int e = e0; e < e1; e += 4) {
+    float a[4]; Spmm8 x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ee = min(e + q, e1 - 1);
+      a[q] = (e + q < e1) ? vals[ee] : 0.f;
+      x[q] = spmm_ld8(X, (long)colidx[ee] * J8 + j, XBF);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc.v[c] += a[q] * x[q].v[c];
+  }
+  if (YBF) {
+    reinterpret_cast<uint4*>(Y)[(long)row * J8 + j] =
+        make_uint4(spmm_pack2(acc.v[0], acc.v[1]), spmm_pack2(acc.v[2], acc.v[3]), spmm_pack2(acc.v[4], acc.v[5]),
+                   spmm_pack2(acc.v[6], acc.v[7]));
+  } else {
+    float4* y = reinterpret_cast<float4*>(Y) + 2 * ((long)row * J8 + j);
+    y[0] = make_float4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
+    y[1] = make_float4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
+  }
+}
 extern "C" int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const float* vals, int n_rows,
-                           const float* X, float* Y, long J, int beta, void* stream) {
+                           const void* X, void* Y, long J, int beta, int x_bf16, int y_bf16, void* stream) {
   MO_CHECK_ARG(rowptr && colidx && vals && X && Y && n_rows > 0 && J > 0 && (J % 4) == 0);
   MO_CHECK_ARG((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 15) == 0);
-  long J4 = J / 4;
-  const int n_panels = mo_cdiv(J4, SPMM_PANEL);
+  hipStream_t st = ST(stream);
+  if (!x_bf16 && !y_bf16) {
+    const long J4 = J / 4;
+    const int n_panels = mo_cdiv(J4, SPMM_PANEL);
+    const long nblk = 8L * n_rows * mo_cdiv(n_panels, 8);
+    MO_CHECK_ARG(nblk < (1L << 31));
+    hipLaunchKernelGGL(spmm_csr_kernel, dim3((unsigned)nblk), dim3(SPMM_PANEL), 0, st, rowptr, colidx, vals,
+                       (const float4*)X, (float4*)Y, J4, n_rows, n_panels, beta);
+    return mo_launch_status();
+  }
+  MO_CHECK_ARG((J % 8) == 0);
+  const long J8 = J / 8;
+  const int n_panels = mo_cdiv(J8, SPMM_PANEL);
   const long nblk = 8L * n_rows * mo_cdiv(n_panels, 8);
   MO_CHECK_ARG(nblk < (1L << 31));
-  hipLaunchKernelGGL(spmm_csr_kernel, dim3((unsigned)nblk), dim3(SPMM_PANEL), 0, ST(stream), rowptr, colidx, vals,
-                     (const float4*)X, (float4*)Y, J4, n_rows, n_panels, beta);
+  dim3 grid((unsigned)nblk), block(SPMM_PANEL);
+  if (x_bf16 && y_bf16)
+    hipLaunchKernelGGL((spmm_csr8_kernel<true, true>), grid, block, 0, st, rowptr, colidx, vals, X, Y, J8, n_rows, n_panels, beta);
+  else if (x_bf16)
+    hipLaunchKernelGGL((spmm_csr8_kernel<true, false>), grid, block, 0, st, rowptr, colidx, vals, X, Y, J8, n_rows, n_panels, beta);
+  else
+    hipLaunchKernelGGL((spmm_csr8_kernel<false, true>), grid, block, 0, st, rowptr, colidx, vals, X, Y, J8, n_rows, n_panels, beta);
   return mo_launch_status();
 }
 
@@ -766,26 +855,30 @@ static bool rs_mlp_ok(const float* const* t, int n, long P) {
   for (int s = 0; s < n; ++s) if (!t[s] || (((uintptr_t)t[s]) & 15)) return false;
   return true;
 }
-static void rs_mlp_launch(bool fwd, int ns, const RsMlpArgs& a, hipStream_t st) {
+static void rs_mlp_launch(bool fwd, int ns, const RsMlpArgs& a, bool bf, hipStream_t st) {
   const long NG = (a.P + 127) / 128;
   long nwg = (NG + 3) / 4;
   if (nwg > 512) nwg = 512;                       // 2 workgroups per CU
   const bool drop = a.drop_thresh != 0;
 #define RS_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)nwg), dim3(256), 0, st, a)
-#define RS_CASE(k) if (ns == k) { \
-    if (fwd) { if (drop) RS_LAUNCH((rs_mlp_fwd_kernel<k, true>)); else RS_LAUNCH((rs_mlp_fwd_kernel<k, false>)); } \
-    else { if (drop) RS_LAUNCH((rs_mlp_bwd_kernel<k, true>)); else RS_LAUNCH((rs_mlp_bwd_kernel<k, false>)); } \
-    return; }
+#define RS_CASE2(k, B) \
+    if (fwd) { if (drop) RS_LAUNCH((rs_mlp_fwd_kernel<k, true, B>)); else RS_LAUNCH((rs_mlp_fwd_kernel<k, false, B>)); } \
+    else { if (drop) RS_LAUNCH((rs_mlp_bwd_kernel<k, true, B>)); else RS_LAUNCH((rs_mlp_bwd_kernel<k, false, B>)); }
+#define RS_CASE(k) if (ns == k) { if (bf) { RS_CASE2(k, true) } else { RS_CASE2(k, false) } return; }
   RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
 #undef RS_LAUNCH
 #undef RS_CASE
+#undef RS_CASE2
 }
+// bf16-storage masks of the mlp entry points: none, or every source but the first
+static bool rs_mask_ok(int mask, int ns) { return mask == 0 || (ns > 1 && mask == (((1 << ns) - 1) & ~1)); }
 
 extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, const float* b, long G, int Tout,
                               int Tin, const float* res, const float* rscale, const float* rshift,
                               uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* h,
-                              float* partial, void* stream) {
+                              float* partial, int src_bf16_mask, void* stream) {
   MO_CHECK_ARG(srcs && W && b && res && h && partial && ns >= 1 && ns <= MO_MAX_SEG && G > 0);
+  MO_CHECK_ARG(rs_mask_ok(src_bf16_mask, ns));
   MO_CHECK_ARG(Tout > 0 && Tin >= Tout && G * Tin < (1L << 31));
   MO_CHECK_ARG((rscale == nullptr) == (rshift == nullptr));
   const long P = G * Tout;
@@ -796,9 +889,10 @@ extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, 
     a.out[0] = h; a.W = W; a.bias = b; a.res = res; a.rscale = rscale; a.rshift = rshift; a.partial = partial;
     a.P = P; a.Tout = Tout; a.Tin = Tin;
     a.drop_seed = drop_seed; a.drop_thresh = drop_thresh; a.drop_scale = drop_scale;
-    rs_mlp_launch(true, ns, a, ST(stream));
+    rs_mlp_launch(true, ns, a, src_bf16_mask != 0, ST(stream));
     return mo_launch_status();
   }
+  if (src_bf16_mask) return MO_EUNSUPPORTED;     // bf16 storage exists on the row-streaming path only
   MoOperand A; op_init(A);
   A.nseg = ns; A.segw = 32; A.rows = (int)P; A.cols = 32 * ns;
   for (int s = 0; s < ns; ++s) { seg_init(A.seg[s], srcs[s], 32); }
@@ -977,9 +1071,11 @@ __global__ void mlp_bias_grad_kernel(const float* __restrict__ dh, long P, uint3
 
 extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrcs, int ns,
                               const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
-                              float* dW, float* db, float* ws, void* dlast_bf16, int parts, void* stream) {
+                              float* dW, float* db, float* ws, void* dlast_bf16, int parts, int src_bf16_mask,
+                              int dsrc_bf16_mask, void* stream) {
   MO_CHECK_ARG(dh && srcs && dsrcs && W && dW && db && ns >= 1 && ns <= MO_MAX_SEG && P > 0 && P < (1L << 31));
   MO_CHECK_ARG(ws || !(parts & 2));
+  MO_CHECK_ARG(rs_mask_ok(src_bf16_mask, ns) && rs_mask_ok(dsrc_bf16_mask, ns));
   hipStream_t st = ST(stream);
   // data: dsrcs[s][p][c] = sum_co dm[p][co] W[co][s*32+c]
   MoOperand A = op_simple(dh, 32, P, 32);                 // XROWS rows = p, cols = k = co
@@ -995,8 +1091,9 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
     a.src[0] = dh; a.W = W; a.P = P; a.out_bf = (unsigned short*)dlast_bf16;
     for (int s = 0; s < ns; ++s) a.out[s] = dsrcs[s];
     a.drop_seed = drop_seed; a.drop_thresh = drop_thresh; a.drop_scale = drop_scale;
-    rs_mlp_launch(false, ns, a, st);
+    rs_mlp_launch(false, ns, a, dsrc_bf16_mask != 0, st);
   } else if (parts & 1) {
+    if (dsrc_bf16_mask) return MO_EUNSUPPORTED;
     if (ns == 1)
       rc = launch<128, 32, 32, 4, 1, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, 32, 1, st);
     else
@@ -1009,7 +1106,8 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
   A2.seg[0].drop_seed = drop_seed; A2.seg[0].drop_thresh = drop_thresh; A2.seg[0].drop_scale = drop_scale;
   MoOperand B2; op_init(B2);
   B2.nseg = ns; B2.segw = 32; B2.rows = (int)P; B2.cols = 32 * ns;
-  for (int s = 0; s < ns; ++s) seg_init(B2.seg[s], srcs[s], 32);
+  for (int s = 0; s < ns; ++s) { seg_init(B2.seg[s], srcs[s], 32); B2.seg[s].bf16 = (src_bf16_mask >> s) & 1; }
+  if (src_bf16_mask && !rsw_ok(A2, B2, P, 32, 32 * ns)) return MO_EUNSUPPORTED;
   bool done = false;
   rc = wgrad_run(A2, B2, P, 32, 32 * ns, ws, dW, db, st, &done);
   if (rc) return rc;

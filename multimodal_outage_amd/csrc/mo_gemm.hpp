@@ -31,7 +31,7 @@ struct MoSeg {
   int relu;
   uint32_t drop_seed, drop_thresh;  // drop_thresh==0: no dropout; element index = srow*ld + col
   float drop_scale;
-  int pad_;
+  int bf16;            // 1: the segment is stored as bf16 (row-streaming kernels only; the tile engine rejects it)
 };
 
 struct MoOperand {

@@ -19,7 +19,7 @@ __host__ __device__ constexpr int rsw_u(int MA, int NB) {
   return 48 / (MA + NB) > 12 ? 12 : (48 / (MA + NB) < 2 ? 2 : 48 / (MA + NB));
 }
 
-template <int MA, int NB, bool MAPPED>
+template <int MA, int NB, bool MAPPED, bool BBF = false>     // BBF: b segments 1.. are stored as bf16
 __global__ __launch_bounds__(256, 2) void rs_wgrad_kernel(MoOperand A, MoOperand B, float* __restrict__ slab,
                                                          float* __restrict__ cs, long P, int post_b) {
   extern __shared__ float rs_sm[];
@@ -88,7 +88,13 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_kernel(MoOperand A, MoOperand
         v = ok & ((unsigned)tt < (unsigned)B.seg[j].Ti);
         srow = v ? g * B.seg[j].Ti + tt : 0;
       }
-      rb[u][j] = mo_gload(B.seg[j].ptr + srow * 32 + c);
+      if (BBF && j > 0) {
+        const unsigned short hv = *(const __attribute__((address_space(1))) unsigned short*)(uintptr_t)(
+            reinterpret_cast<const unsigned short*>(B.seg[j].ptr) + srow * 32 + c);
+        rb[u][j] = __uint_as_float(((unsigned)hv) << 16);
+      } else {
+        rb[u][j] = mo_gload(B.seg[j].ptr + srow * 32 + c);
+      }
       okm |= (v ? 1u : 0u) << j;
     }
     bok[u] = okm;
@@ -250,6 +256,38 @@ __device__ __forceinline__ void rs_issue_block(float4 (&v)[4], __amdgpu_buffer_r
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = rs_load4(r, base + 1024u * j);
 }
+// bf16-stored [.][32] rows (64 B): two 16-byte loads cover the 32-row tile, load j = rows 16j + (lane>>2), eight
+// columns from 8*(lane&3); lane_off_bf = (lane>>2)*64 + (lane&3)*16.  The raw bits wait in v[0..1].
+__device__ __forceinline__ void rs_issue_block_bf(float4 (&v)[4], __amdgpu_buffer_rsrc_t r, long row0, unsigned lane_off_bf) {
+  const unsigned base = (unsigned)(row0 * 64) + lane_off_bf;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) v[j] = rs_load4(r, base + 1024u * j);
+}
+__device__ __forceinline__ void rs_put_bf(float* X, const float4 (&v)[4], int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned u0 = __float_as_uint(v[j].x), u1 = __float_as_uint(v[j].y), u2 = __float_as_uint(v[j].z),
+                   u3 = __float_as_uint(v[j].w);
+    float* d = &X[(16 * j + (lane >> 2)) * RS_LDX + 8 * (lane & 3)];
+    *reinterpret_cast<float4*>(d) = make_float4(__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u),
+                                                __uint_as_float(u1 << 16), __uint_as_float(u1 & 0xffff0000u));
+    *reinterpret_cast<float4*>(d + 4) = make_float4(__uint_as_float(u2 << 16), __uint_as_float(u2 & 0xffff0000u),
+                                                    __uint_as_float(u3 << 16), __uint_as_float(u3 & 0xffff0000u));
+  }
+}
+// Two accumulator registers holding rows i, i+1 of a 32x32 tile (r even) as bf16: neighbouring lanes swap one
+// value (DPP quad_perm [1,0,3,2]) so that every lane stores one packed dword -- even lanes row i, odd lanes
+// row i+1 -- instead of two 2-byte stores.  elem0 = element index of (row i, column 0).
+__device__ __forceinline__ void rs_store_bf16_pair(__amdgpu_buffer_rsrc_t r, long elem0, int n, float v0, float v1) {
+  const bool odd = n & 1;
+  const float send = odd ? v0 : v1;
+  const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0xB1, 0xf, 0xf, true));
+  const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
+  __bf16 tl = (__bf16)lo, th = (__bf16)hi;
+  const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, tl) | ((unsigned)__builtin_bit_cast(unsigned short, th) << 16);
+  const long e = elem0 + (odd ? 32 : 0) + (n & ~1);
+  __builtin_amdgcn_raw_buffer_store_b32(pk, r, (int)(unsigned)(e * 2), 0, 0);
+}
 __device__ __forceinline__ void rs_put(float* X, const float4 (&v)[4], int lane) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -264,7 +302,7 @@ __device__ __forceinline__ void rs_get(const float* X, float (&a)[16], int lane)
   }
 }
 
-template <int NS, bool DROP>
+template <int NS, bool DROP, bool SBF>      // SBF: sources 1.. are stored as bf16 (source 0, the gated TCN output, fp32)
 __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
   __shared__ float Ws[NS * 32 * RS_LDW];
   __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
@@ -291,16 +329,21 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
   const __amdgpu_buffer_rsrc_t resr = rs_rsrc(a.res, (P / To) * Ti * 128);
   __amdgpu_buffer_rsrc_t srcr[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) srcr[s] = rs_rsrc(a.src[s], P * 128);
+  for (int s = 0; s < NS; ++s) srcr[s] = rs_rsrc(a.src[s], P * ((SBF && s > 0) ? 64 : 128));
   const unsigned lane_off = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16);
+  const unsigned lane_off_bf = (unsigned)((lane >> 2) * 64 + (lane & 3) * 16);
 
   // Ring of RS_R (block, source) tiles in flight per wave, 4 KB each; step i = 4*NS*run + NS*jb + s lives in
   // slot i % RS_R (static: RS_R divides 4*NS) and is refilled with step i + RS_R as soon as it sits in LDS.
   constexpr int RS_R = 4;
   float4 ring[RS_R][4];
   auto step_row0 = [&](long gi, int i) -> long { return gi * 128 + (i / NS) * 32; };   // i in [0, 4*NS)
+  auto issue_step = [&](float4 (&dst)[4], long gi, int i) {
+    if (SBF && (i % NS) > 0) rs_issue_block_bf(dst, srcr[i % NS], step_row0(gi, i), lane_off_bf);
+    else rs_issue_block(dst, srcr[i % NS], step_row0(gi, i), lane_off);
+  };
 #pragma unroll
-  for (int i = 0; i < RS_R; ++i) rs_issue_block(ring[i], srcr[i % NS], step_row0(w, i), lane_off);
+  for (int i = 0; i < RS_R; ++i) issue_step(ring[i], w, i);
 
   for (long gi = w; gi < NG; gi += nwaves) {
     const long gnext = (gi + nwaves < NG) ? gi + nwaves : gi;     // tail: harmless re-read of the own run
@@ -327,12 +370,11 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
       for (int s = 0; s < NS; ++s) {
         const int i = jb * NS + s;                 // step within the run
         const int slot = i % RS_R;
-        rs_put(X, ring[slot], lane);
+        if (SBF && s > 0) rs_put_bf(X, ring[slot], lane);
+        else rs_put(X, ring[slot], lane);
         {
           const int in = i + RS_R;                 // the step this slot serves next
-          const long g2 = (in < 4 * NS) ? gi : gnext;
-          const int i2 = in % (4 * NS);
-          rs_issue_block(ring[slot], srcr[i2 % NS], step_row0(g2, i2), lane_off);
+          issue_step(ring[slot], (in < 4 * NS) ? gi : gnext, in % (4 * NS));
         }
         float av[16];
         rs_get(X, av, lane);
@@ -363,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
 }
 
 // data gradient: dsrc[s][p][:] = dm[p][:] @ W[:, 32s:32s+32], dm = dropout-masked dh
-template <int NS, bool DROP>
+template <int NS, bool DROP, bool OBF>      // OBF: gradients of sources 1.. are bf16 tensors (source 0 fp32)
 __global__ __launch_bounds__(256, 2) void rs_mlp_bwd_kernel(RsMlpArgs a) {
   __shared__ float Ws[32 * (NS * 32 + 1)];       // [k = co][n], row stride 32*NS+1
   __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
@@ -415,13 +457,22 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_bwd_kernel(RsMlpArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[(16 * half + t) * LW + s * 32 + n], acc, 0, 0, 0);
-        const __amdgpu_buffer_rsrc_t o = rs_rsrc(a.out[s], P * 128);
-        const __amdgpu_buffer_rsrc_t ob = rs_rsrc(a.out_bf, a.out_bf ? P * 64 : 0);
+        if (OBF && s > 0) {
+          const __amdgpu_buffer_rsrc_t o = rs_rsrc(a.out[s], P * 64);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          rs_store_f32(o, m * 32 + n, acc[r]);
-          if (s == NS - 1) rs_store_bf16(ob, m * 32 + n, acc[r]);     // num_records 0 when absent: dropped
+          for (int r = 0; r < 16; r += 2) {
+            const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            rs_store_bf16_pair(o, m * 32, n, acc[r], acc[r + 1]);
+          }
+        } else {
+          const __amdgpu_buffer_rsrc_t o = rs_rsrc(a.out[s], P * 128);
+          const __amdgpu_buffer_rsrc_t ob = rs_rsrc(a.out_bf, a.out_bf ? P * 64 : 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            rs_store_f32(o, m * 32 + n, acc[r]);
+            if (s == NS - 1) rs_store_bf16(ob, m * 32 + n, acc[r]);     // num_records 0 when absent: dropped
+          }
         }
         __builtin_amdgcn_sched_barrier(0);     // one accumulator tile at a time (register budget)
       }

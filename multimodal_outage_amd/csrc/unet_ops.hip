@@ -12,7 +12,7 @@
 
 static void useg(MoSeg& s, const float* ptr, long istride, const float* sc, const float* sh, int relu) {
   s.ptr = ptr; s.scale = sc; s.shift = sh; s.ld = (int)istride;
-  s.To = 0; s.Ti = 0; s.off = 0; s.relu = relu; s.drop_seed = 0; s.drop_thresh = 0; s.drop_scale = 1.f; s.pad_ = 0;
+  s.To = 0; s.Ti = 0; s.off = 0; s.relu = relu; s.drop_seed = 0; s.drop_thresh = 0; s.drop_scale = 1.f; s.bf16 = 0;
 }
 static void uop(MoOperand& o, long rows, long cols) {
   for (int i = 0; i < MO_MAX_SEG; ++i) useg(o.seg[i], nullptr, 0, nullptr, nullptr, 0);

@@ -176,8 +176,17 @@ class _WgradLane:
 
 
 def _spmm(csr, n, X, Y, J, beta):
+    """Y (+)= S @ X over nbtc rows; the storage type of each side (fp32 / bf16) follows the tensors."""
     L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), n, L.ptr(X), L.ptr(Y), J, beta,
-           L.stream())
+           int(X.dtype == torch.bfloat16), int(Y.dtype == torch.bfloat16), L.stream())
+
+
+def _bf_mask(ts):
+    m = 0
+    for k, t in enumerate(ts):
+        if t.dtype == torch.bfloat16:
+            m |= 1 << k
+    return m
 
 
 class GwnetFunction(torch.autograd.Function):
@@ -242,25 +251,27 @@ class GwnetFunction(torch.autograd.Function):
                 # (static CSR, HBM-bound) branch; both only read g and are joined in front of the mlp
                 side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap and not SERIAL) else None
                 dense_out = []
+                # bf16 mode keeps every diffusion intermediate (and, in backward, its gradient) as a bf16
+                # tensor only: the row-streaming kernels widen on load and narrow on store
+                idt = torch.bfloat16 if use_bf else torch.float32
                 if cfg.adaptive:
-                    x1 = _e(P, 32, dev)
-                    x2 = _e(P, 32, dev)
+                    x1 = torch.empty((P, 32), device=dev, dtype=idt)
+                    x2 = torch.empty((P, 32), device=dev, dtype=idt)
                     main = torch.cuda.current_stream()
                     if side is not None:
                         side.wait_stream(main)
                     with torch.cuda.stream(side if side is not None else main):
                         if use_bf:
-                            x1_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
-                            _adj_prod(adpT_bf, g_bf, x1, N, J, 0, x1_bf)
-                            _adj_prod(adpT_bf, x1_bf, x2, N, J, 0)
-                            bf_saved = (g_bf, x1_bf)
+                            _adj_prod(adpT_bf, g_bf, None, N, J, 0, x1)
+                            _adj_prod(adpT_bf, x1, None, N, J, 0, x2)
+                            bf_saved = (g_bf, x1)
                         else:
                             _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(g), L.ptr(x1), J, 0, L.stream())
                             _dense('mo_adj_gemm', N, J, L.ptr(adp), N, L.ptr(x1), L.ptr(x2), J, 0, L.stream())
                     dense_out = [x1, x2]
                 for s in statics:
-                    x1 = _e(P, 32, dev)
-                    x2 = _e(P, 32, dev)
+                    x1 = torch.empty((P, 32), device=dev, dtype=idt)
+                    x2 = torch.empty((P, 32), device=dev, dtype=idt)
                     _spmm(s.fwd, N, g, x1, J, 0)
                     _spmm(s.fwd, N, x1, x2, J, 0)
                     srcs += [x1, x2]
@@ -276,7 +287,8 @@ class GwnetFunction(torch.autograd.Function):
             nblk = (P + 127) // 128
             partial = torch.empty(L.load().mo_mlp_partial_floats(P), device=dev, dtype=torch.float32)
             L.call('mo_gcn_mlp_fwd', L.ptr_array(srcs), len(srcs), L.ptr(W), L.ptr(bb), G, Tout, Tin,
-                   L.ptr(h), L.ptr(scale), L.ptr(shift), seed, lt, ls, L.ptr(hn), L.ptr(partial), st)
+                   L.ptr(h), L.ptr(scale), L.ptr(shift), seed, lt, ls, L.ptr(hn), L.ptr(partial),
+                   _bf_mask(srcs), st)
             stats = torch.empty(4, 32, device=dev, dtype=torch.float32)   # scale, shift, mean, rstd
             rm, rv = bn_bufs[i]
             L.call('mo_bn_finalize', L.ptr(partial), nblk, P, L.ptr(p[f'bn.{i}.weight']),
@@ -389,7 +401,8 @@ class GwnetFunction(torch.autograd.Function):
                        L.ptr(wsb), st)
                 grads[f'bn.{i}.weight'], grads[f'bn.{i}.bias'] = gg, gb
                 # mlp / residual-conv backward (graph_wavenet.py:95-97 / :245)
-                dsrcs = [_e(P, 32, dev) for _ in range(ns)]
+                dsrcs = [torch.empty((P, 32), device=dev, dtype=sr.dtype) for sr in srcs]
+                smask = _bf_mask(srcs)
                 if cfg.gcn:
                     W = p[f'gconv.{i}.mlp.mlp.weight']
                     kW, kb = f'gconv.{i}.mlp.mlp.weight', f'gconv.{i}.mlp.mlp.bias'
@@ -397,15 +410,14 @@ class GwnetFunction(torch.autograd.Function):
                     W = p[f'residual_convs.{i}.weight']
                     kW, kb = f'residual_convs.{i}.weight', f'residual_convs.{i}.bias'
                 gW = gbuf(kW, W); gbm = gbuf(kb, shape=(32,))
-                dx2_bf = (torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
-                          if (ly['bf'] is not None and cfg.gcn and cfg.adaptive) else None)
                 L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
-                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), None, L.ptr(dx2_bf), 1, st)
+                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), None, None, 1, smask, smask,
+                       st)
 
-                def _mlp_w(dh=dh, srcs=srcs, dsrcs=dsrcs, ns=ns, W=W, P=P, ly=ly, gW=gW, gbm=gbm):
+                def _mlp_w(dh=dh, srcs=srcs, dsrcs=dsrcs, ns=ns, W=W, P=P, ly=ly, gW=gW, gbm=gbm, smask=smask):
                     L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
                            ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm),
-                           L.ptr(ws_for(32, 32 * ns, P)), None, 2, L.stream())
+                           L.ptr(ws_for(32, 32 * ns, P)), None, 2, smask, smask, L.stream())
                 lane.run(_mlp_w, reads=(dh,))
                 grads[kW], grads[kb] = gW, gbm
                 dg = dsrcs[0]
@@ -423,8 +435,8 @@ class GwnetFunction(torch.autograd.Function):
                         with torch.cuda.stream(side if side is not None else main):
                             if ly['bf'] is not None:
                                 g_bf, x1_bf = ly['bf']
-                                dx1_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16)
-                                _adj_prod(ctx.adp_bf, dx2_bf, dx1, N, J, 1, dx1_bf)
+                                dx1_bf, dx2_bf = dx1, dx2          # already bf16 tensors
+                                _adj_prod(ctx.adp_bf, dx2_bf, None, N, J, 1, dx1_bf)
                                 # only dx1 is needed by the main chain; the two dA accumulations keep running
                                 # on the side stream beside the rest of this layer's backward
                                 if side is not None:

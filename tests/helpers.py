@@ -79,3 +79,17 @@ def check_grads_vs_f64(named_grads, G, factor=3.0, floor=2e-4):
         if e_gpu > worst[0]:
             worst = (e_gpu, k)
     return worst
+
+
+def dropout_keep_mask(seed, thresh, n):
+    """Host restatement of the engine's counter-based dropout mask (csrc/mo_common.h: mo_hash32): element idx is kept
+    iff hash(seed, idx) >= thresh.  Returns a bool array of n elements."""
+    M = 0xFFFFFFFF
+    x = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed)) & np.uint64(M)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(M)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(M)
+    x ^= x >> np.uint64(16)
+    x = (x + np.uint64((seed * 0x85ebca6b) & M)) & np.uint64(M)
+    x ^= x >> np.uint64(13); x = (x * np.uint64(0xc2b2ae35)) & np.uint64(M)
+    x ^= x >> np.uint64(16)
+    return x >= np.uint64(thresh)

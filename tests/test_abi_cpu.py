@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.mo_version() >= 1
     assert lib.mo_strerror(-1) == b'invalid argument'
     # argument validation happens before any device work: NULL pointers are rejected on a CPU-only host
-    assert lib.mo_spmm_csr(None, None, None, 0, None, None, 0, 0, None) == -1
+    assert lib.mo_spmm_csr(None, None, None, 0, None, None, 0, 0, 0, 0, None) == -1
     assert lib.mo_conv1x1_fwd(None, 0, 0, 0, 0, 0, None, None, 0, None, 0, 0, 0, None) == -1
 
 

@@ -245,8 +245,23 @@ def test_spmm_and_dense_products(L, N, J):
     for beta in (0, 1):
         Y = dev(Y0.clone())
         L.call('mo_spmm_csr', L.ptr(dev(torch.from_numpy(rp))), L.ptr(dev(torch.from_numpy(ci))),
-               L.ptr(dev(torch.from_numpy(va))), N, L.ptr(dev(X)), L.ptr(Y), J, beta, L.stream())
+               L.ptr(dev(torch.from_numpy(va))), N, L.ptr(dev(X)), L.ptr(Y), J, beta, 0, 0, L.stream())
         close(Y, ref + (Y0 if beta else 0), what=f'spmm beta={beta}')
+    # bf16-stored operands (fp32 accumulate): inputs are exactly representable, outputs round once
+    Xb, Y0b = X.to(torch.bfloat16), Y0.to(torch.bfloat16)
+    refb = torch.from_numpy(A).t() @ Xb.float()
+    for xbf, ybf in ((1, 0), (0, 1), (1, 1)):
+        for beta in (0, 1):
+            Y = dev(Y0b.clone() if ybf else Y0.clone())
+            L.call('mo_spmm_csr', L.ptr(dev(torch.from_numpy(rp))), L.ptr(dev(torch.from_numpy(ci))),
+                   L.ptr(dev(torch.from_numpy(va))), N, L.ptr(dev(Xb if xbf else X)), L.ptr(Y), J, beta, xbf, ybf,
+                   L.stream())
+            want = (refb if xbf else ref) + ((Y0b.float() if ybf else Y0) if beta else 0)
+            if ybf:
+                assert Y.dtype == torch.bfloat16
+                close(Y.float(), want, 8e-3, what=f'spmm bf16 x={xbf} y={ybf} beta={beta}')
+            else:
+                close(Y, want, what=f'spmm bf16 x={xbf} beta={beta}')
     if N <= 400:
         D = rand(32, (N, N)) / np.sqrt(N)
         for beta in (0, 1):
@@ -300,7 +315,7 @@ def test_gcn_mlp_bn(L, B, N, Tin, Tout, ns, drop, affine):
     sd = [dev(s) for s in srcs]
     L.call('mo_gcn_mlp_fwd', L.ptr_array(sd), ns, L.ptr(dev(W)), L.ptr(dev(b)), G, Tout, Tin, L.ptr(dev(res)),
            L.ptr(dev(sc)) if affine else None, L.ptr(dev(sh)) if affine else None, seed, thresh, dscale,
-           L.ptr(h), L.ptr(partial), L.stream())
+           L.ptr(h), L.ptr(partial), 0, L.stream())
     hc = h.cpu()
     if drop == 0.0:
         href = m + resc
@@ -363,13 +378,63 @@ def test_gcn_mlp_bn(L, B, N, Tin, Tout, ns, drop, affine):
     wsm = torch.empty(lib.mo_wgrad_ws_floats(32, 32 * ns, P), device='cuda')
     dlast_bf = torch.empty(P, 32, device='cuda', dtype=torch.bfloat16)
     L.call('mo_gcn_mlp_bwd', L.ptr(dev(dhh)), L.ptr_array(sd), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P,
-           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), L.ptr(dlast_bf), 3, L.stream())
+           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), L.ptr(dlast_bf), 3, 0, 0, L.stream())
     assert torch.equal(dlast_bf.cpu(), dsrcs[ns - 1].cpu().to(torch.bfloat16))
     for s in range(ns):
         close(dsrcs[s], dcat[:, 32 * s:32 * (s + 1)], what=f'dsrc{s}')
     close(dW, dm.t() @ cat, what='dWm')
     close(db, dm.sum(0), what='dbm')
 
+
+
+@pytest.mark.parametrize('B,N,Tin,Tout,ns,drop', [(4, 20, 13, 12, 7, 0.0), (2, 67, 7, 7, 5, 0.3), (3, 37, 9, 7, 3, 0.0)])
+def test_gcn_mlp_bf16_storage(L, B, N, Tin, Tout, ns, drop):
+    """Sources 1.. and their gradients stored as bf16 tensors (bf16 mode of the engine): the loader widens,
+    the epilogue narrows; source 0 (the gated TCN output) stays fp32."""
+    lib = L.load()
+    G = N * B
+    P = G * Tout
+    mask = ((1 << ns) - 1) & ~1
+    srcs = [rand(40 + s, (P, 32)) for s in range(ns)]
+    srcs = [s_ if k == 0 else s_.to(torch.bfloat16) for k, s_ in enumerate(srcs)]
+    W = rand(50, (32, 32 * ns)) / np.sqrt(32 * ns)
+    b = rand(51, (32,))
+    res = rand(52, (G * Tin, 32))
+    cat = torch.cat([s_.float() for s_ in srcs], dim=1)
+    m = cat @ W.t() + b
+    resc = _rowmap(res, G, Tout, Tin, Tin - Tout)
+    thresh = int(drop * 4294967296.0) if drop > 0 else 0
+    dscale = 1.0 / (1.0 - drop) if drop > 0 else 1.0
+    seed = 777
+    h = torch.empty(P, 32, device='cuda')
+    partial = torch.empty(lib.mo_mlp_partial_floats(P), device='cuda')
+    sd = [dev(s_) for s_ in srcs]
+    L.call('mo_gcn_mlp_fwd', L.ptr_array(sd), ns, L.ptr(dev(W)), L.ptr(dev(b)), G, Tout, Tin, L.ptr(dev(res)),
+           None, None, seed, thresh, dscale, L.ptr(h), L.ptr(partial), mask, L.stream())
+    hc = h.cpu()
+    if drop == 0.0:
+        close(hc, m + resc, what='h (bf16 sources)')
+        keep = torch.ones_like(m)
+    else:
+        from helpers import dropout_keep_mask
+        kept = torch.from_numpy(dropout_keep_mask(seed, thresh, P * 32).reshape(P, 32))
+        keep = kept.float() * dscale
+        close(hc, m * keep + resc, what='h (bf16 sources, dropout)')
+        assert abs(1.0 - kept.float().mean().item() - drop) < 0.02
+    dhh = rand(60, (P, 32))
+    dm = dhh * keep
+    dcat = dm @ W
+    dsrcs = [torch.empty(P, 32, device='cuda', dtype=s_.dtype) for s_ in srcs]
+    dW = torch.empty(32, 32 * ns, device='cuda'); db = torch.empty(32, device='cuda')
+    wsm = torch.empty(lib.mo_wgrad_ws_floats(32, 32 * ns, P), device='cuda')
+    L.call('mo_gcn_mlp_bwd', L.ptr(dev(dhh)), L.ptr_array(sd), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P,
+           seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), None, 3, mask, mask, L.stream())
+    close(dsrcs[0], dcat[:, :32], what='dsrc0 (fp32)')
+    for s_ in range(1, ns):
+        assert dsrcs[s_].dtype == torch.bfloat16
+        close(dsrcs[s_].float(), dcat[:, 32 * s_:32 * (s_ + 1)], 8e-3, what=f'dsrc{s_} (bf16)')
+    close(dW, dm.t() @ cat, what='dWm (bf16 sources)')
+    close(db, dm.sum(0), what='dbm')
 
 def test_metrics_and_grad(L):
     lib = L.load()
@@ -443,6 +508,12 @@ def test_gemm_bf16(L, M, N, K, krows):
                beta, L.ptr(Dbf), L.stream())
         assert torch.equal(Dbf.cpu(), D.cpu().to(torch.bfloat16))
         close(D, ref + (D0 if beta else 0), 2e-5, f'gemm_bf16 beta={beta}')
+        # bf16-only result (D == NULL): beta accumulates onto the stored bf16 values
+        D0b = D0.to(torch.bfloat16)
+        Donly = dev(D0b.clone())
+        L.call('mo_gemm_bf16', L.ptr(Ab), K, L.ptr(Bb), N if krows else K, 1 if krows else 0, None, N, M, N, K,
+               beta, L.ptr(Donly), L.stream())
+        close(Donly.float(), ref + (D0b.float() if beta else 0), 8e-3, f'gemm_bf16 bf16-only beta={beta}')
 
 
 @pytest.mark.parametrize('M,N,K,krows', [(256, 256, 32, True), (3000, 1536, 3000, True), (300, 264, 296, True),
@@ -469,3 +540,8 @@ def test_gemm_bf16_256_dma_ring(L, M, N, K, krows):
         if beta:
             assert torch.equal(Dbf.cpu(), D.cpu().to(torch.bfloat16))
         close(D, ref + (D0 if beta else 0), 2e-5, f'gemm_bf16_256 beta={beta}')
+        D0b = D0.to(torch.bfloat16)
+        Donly = dev(D0b.clone())
+        L.call('mo_gemm_bf16_256', L.ptr(Ab), kpad, kpad, L.ptr(Bb), N if krows else K, 1 if krows else 0, None, N,
+               M, N, K, beta, L.ptr(Donly), L.stream())
+        close(Donly.float(), ref + (D0b.float() if beta else 0), 8e-3, f'gemm_bf16_256 bf16-only beta={beta}')

@@ -74,22 +74,22 @@ if want('spmm'):
     csr = [torch.from_numpy(x).to(dev) for x in (rp, ci, va)]
     X, Y = srcs[0], srcs[1]
     ms = timeit(lambda: L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), N, L.ptr(X), L.ptr(Y), J,
-                               0, st))
+                               0, 0, 0, st))
     report(f'spmm_csr beta=0 (nnz {len(va)})', ms, 2 * row)
     ms = timeit(lambda: L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), N, L.ptr(X), L.ptr(Y), J,
-                               1, st))
+                               1, 0, 0, st))
     report('spmm_csr beta=1', ms, 3 * row)
     rpI, ciI, vaI = csr_from_dense(np.eye(N, dtype=np.float32))
     csrI = [torch.from_numpy(x).to(dev) for x in (rpI, ciI, vaI)]
     ms = timeit(lambda: L.call('mo_spmm_csr', L.ptr(csrI[0]), L.ptr(csrI[1]), L.ptr(csrI[2]), N, L.ptr(X), L.ptr(Y), J,
-                               0, st))
+                               0, 0, 0, st))
     report('spmm_csr identity (pure copy)', ms, 2 * row)
     ms = timeit(lambda: Y.copy_(X))
     report('torch copy_', ms, 2 * row)
 
 if want('mlp_fwd'):
     ms = timeit(lambda: L.call('mo_gcn_mlp_fwd', L.ptr_array(srcs), ns, L.ptr(W), L.ptr(b), G, Tout, Tin,
-                               L.ptr(res), L.ptr(sc), L.ptr(sh), 1, thresh, dscale, L.ptr(h), L.ptr(partial), st))
+                               L.ptr(res), L.ptr(sc), L.ptr(sh), 1, thresh, dscale, L.ptr(h), L.ptr(partial), 0, st))
     report('gcn_mlp_fwd (7 src + res -> h)', ms, (ns + 2) * row)
 
 dh = torch.randn(P, 32, device=dev)
@@ -99,10 +99,10 @@ wsm = torch.empty(lib.mo_wgrad_ws_floats(32, 32 * ns, P), device=dev)
 dlast = torch.empty(P, 32, device=dev, dtype=torch.bfloat16)
 if want('mlp_bwd'):
     ms = timeit(lambda: L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
-                               1, thresh, dscale, L.ptr(dW), L.ptr(db), None, L.ptr(dlast), 1, st))
+                               1, thresh, dscale, L.ptr(dW), L.ptr(db), None, L.ptr(dlast), 1, 0, 0, st))
     report('gcn_mlp_bwd data (dh -> 7 dsrc)', ms, (ns + 1) * row + row // 2)
     ms = timeit(lambda: L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
-                               1, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), None, 2, st))
+                               1, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), None, 2, 0, 0, st))
     report('gcn_mlp_bwd wgrad (dh, 7 src)', ms, (ns + 1) * row)
 
 if want('tcn'):
@@ -157,3 +157,33 @@ if want('skip'):
     ms = timeit(lambda: L.call('mo_conv1x1_bwd_data', L.ptr(skip), Cs, Pf, L.ptr(Ws), 32, L.ptr(dsrcs[0]), Tf, Tout,
                                Tout - Tf, None, 1, st))
     report('skip conv bwd data (beta=1)', ms, Pf * (Cs + 64) * 4)
+
+if want('bf16'):
+    # the same ops with the diffusion intermediates stored as bf16 (throughput mode)
+    srcs_b = [srcs[0]] + [s_.to(torch.bfloat16) for s_ in srcs[1:]]
+    mask = ((1 << ns) - 1) & ~1
+    ms = timeit(lambda: L.call('mo_gcn_mlp_fwd', L.ptr_array(srcs_b), ns, L.ptr(W), L.ptr(b), G, Tout, Tin,
+                               L.ptr(res), L.ptr(sc), L.ptr(sh), 1, thresh, dscale, L.ptr(h), L.ptr(partial), mask, st))
+    report('bf16-stored: gcn_mlp_fwd', ms, (1 + (ns - 1) / 2 + 2) * row)
+    dsrcs_b = [dsrcs[0]] + [torch.empty(P, 32, device=dev, dtype=torch.bfloat16) for _ in range(ns - 1)]
+    ms = timeit(lambda: L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs_b), L.ptr_array(dsrcs_b), ns, L.ptr(W), P,
+                               1, thresh, dscale, L.ptr(dW), L.ptr(db), None, None, 1, mask, mask, st))
+    report('bf16-stored: gcn_mlp_bwd data', ms, (2 + (ns - 1) / 2) * row)
+    ms = timeit(lambda: L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs_b), L.ptr_array(dsrcs_b), ns, L.ptr(W), P,
+                               1, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), None, 2, mask, mask, st))
+    report('bf16-stored: gcn_mlp_bwd wgrad', ms, (2 + (ns - 1) / 2) * row)
+    Xb, Yb = srcs_b[1], srcs_b[2]
+    rs = np.random.RandomState(0)
+    pos = rs.uniform(size=(N, 2)).astype(np.float32)
+    d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+    idx = np.argsort(d2, axis=1)[:, :6]
+    A = np.zeros((N, N), np.float32)
+    for i in range(N):
+        A[i, idx[i]] = 1.0
+    A = A / A.sum(1, keepdims=True)
+    csr = [torch.from_numpy(x).to(dev) for x in csr_from_dense(A.T)]
+    for (xx, yy, nm, nb) in ((srcs[0], Yb, 'f32->bf16', 1.5), (Xb, Yb, 'bf16->bf16', 1.0), (Xb, srcs[1], 'bf16->f32 beta=1', 2.5)):
+        ms = timeit(lambda: L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), N, L.ptr(xx), L.ptr(yy), J,
+                                   1 if 'beta' in nm else 0, int(xx.dtype == torch.bfloat16),
+                                   int(yy.dtype == torch.bfloat16), st))
+        report(f'bf16-stored: spmm {nm}', ms, nb * row)
