@@ -111,9 +111,14 @@ def _use_ring(M, Ncols):
     return fill * 1070.0 > est128
 
 
+_SKIP = os.environ.get('MO_SKIP', '')     # timing experiments only: drop a kernel class from the step
+
+
 def _adj_prod(A_bf, X_bf, Y, N, J, beta, Y_bf=None):
     """Y[N][J] (+)= A_bf[N][N(k)] @ X_bf[N(k)][J]   (bf16 operands, fp32 accumulate); A_bf is [N][Kpad].
     Y_bf: optional bf16 copy of the result written by the same epilogue."""
+    if 'prod' in _SKIP:
+        return
     kpad = A_bf.shape[1]
     if _use_ring(N, J):
         _dense('mo_gemm_bf16_256', N, J, L.ptr(A_bf), kpad, kpad, L.ptr(X_bf), J, 1, L.ptr(Y), J, N, J, N, beta,
@@ -125,6 +130,8 @@ def _adj_prod(A_bf, X_bf, Y, N, J, beta, Y_bf=None):
 
 def _adj_grad_bf(X_bf, dY_bf, dA, N, J, beta):
     """dA[N][N] (+)= X_bf[N][J] @ dY_bf[N][J]^T."""
+    if 'dA' in _SKIP:
+        return
     if N >= BIG_TILE_MIN_N:
         _dense('mo_gemm_bf16_256', N, J, L.ptr(X_bf), J, J, L.ptr(dY_bf), J, 0, L.ptr(dA), N, N, N, J, beta, None,
                L.stream())
