@@ -302,19 +302,52 @@ __device__ __forceinline__ void rs_get(const float* X, float (&a)[16], int lane)
   }
 }
 
+// ---- bf16-MFMA path of the throughput mode (v_mfma_f32_32x32x16_bf16: 16x fewer MFMA cycles than the exact
+// fp32 32x32x2): the wave-private LDS tile holds bf16 [32 rows][32 k], row stride 80 B (conflict-free b128 reads)
+#define RS_LDXB 40
+typedef short rs_v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 rs_v8bf __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned rs_pack_bf16(float a, float b) {
+  __bf16 ta = (__bf16)a, tb = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ta) | ((unsigned)__builtin_bit_cast(unsigned short, tb) << 16);
+}
+// fp32 tile registers (rs_issue_block layout) -> bf16 LDS tile
+__device__ __forceinline__ void rs_put_f2b(short* Xb, const float4 (&v)[4], int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    *reinterpret_cast<uint2*>(&Xb[(8 * j + (lane >> 3)) * RS_LDXB + 4 * (lane & 7)]) =
+        make_uint2(rs_pack_bf16(v[j].x, v[j].y), rs_pack_bf16(v[j].z, v[j].w));
+}
+// bf16 tile registers (rs_issue_block_bf layout) -> bf16 LDS tile: a straight copy
+__device__ __forceinline__ void rs_put_b2b(short* Xb, const float4 (&v)[4], int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    *reinterpret_cast<float4*>(&Xb[(16 * j + (lane >> 2)) * RS_LDXB + 8 * (lane & 3)]) = v[j];
+}
+// A fragments of the two K=16 MFMAs of a 32-wide contraction: lane = row (lane&31), k = 16h + 8*(lane>>5) + 0..7
+__device__ __forceinline__ void rs_get_b(const short* Xb, rs_v8s (&a)[2], int lane) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    a[h] = *reinterpret_cast<const rs_v8s*>(&Xb[(lane & 31) * RS_LDXB + 16 * h + 8 * (lane >> 5)]);
+}
+
 template <int NS, bool DROP, bool SBF>      // SBF: sources 1.. are stored as bf16 (source 0, the gated TCN output, fp32)
 __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
-  __shared__ float Ws[NS * 32 * RS_LDW];
-  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  // SBF also selects the bf16 MFMA: weights as bf16 [n][k] rows (stride KT+8), tiles as bf16
+  __shared__ __attribute__((aligned(16))) float Ws[SBF ? 16 * (32 * NS + 8) : NS * 32 * RS_LDW];
+  __shared__ __attribute__((aligned(16))) float Xs[4][SBF ? 16 * RS_LDXB : 32 * RS_LDX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, half = lane >> 5;
-  constexpr int KT = 32 * NS;
+  constexpr int KT = 32 * NS, LWB = KT + 8;
+  short* Wb = reinterpret_cast<short*>(Ws);
   for (int idx = tid; idx < 32 * KT; idx += 256) {
     const int co = idx / KT, k = idx - co * KT;
-    Ws[k * RS_LDW + co] = a.W[idx];
+    if (SBF) { __bf16 t = (__bf16)a.W[idx]; Wb[co * LWB + k] = __builtin_bit_cast(short, t); }
+    else Ws[k * RS_LDW + co] = a.W[idx];
   }
   __syncthreads();
   float* X = Xs[wave];
+  short* Xb = reinterpret_cast<short*>(Xs[wave]);
   const long P = a.P;
   const long NG = (P + 127) >> 7;
   const long nwaves = (long)gridDim.x * 4;
@@ -370,17 +403,28 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
       for (int s = 0; s < NS; ++s) {
         const int i = jb * NS + s;                 // step within the run
         const int slot = i % RS_R;
-        if (SBF && s > 0) rs_put_bf(X, ring[slot], lane);
+        if (SBF) { if (s > 0) rs_put_b2b(Xb, ring[slot], lane); else rs_put_f2b(Xb, ring[slot], lane); }
         else rs_put(X, ring[slot], lane);
         {
           const int in = i + RS_R;                 // the step this slot serves next
           issue_step(ring[slot], (in < 4 * NS) ? gi : gnext, in % (4 * NS));
         }
-        float av[16];
-        rs_get(X, av, lane);
+        if (SBF) {
+          rs_v8s av[2];
+          rs_get_b(Xb, av, lane);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[(s * 32 + 16 * half + t) * RS_LDW + n], acc, 0, 0, 0);
+          for (int h = 0; h < 2; ++h) {
+            const rs_v8s bw = *reinterpret_cast<const rs_v8s*>(&Wb[n * LWB + s * 32 + 16 * h + 8 * half]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rs_v8bf, av[h]),
+                                                          __builtin_bit_cast(rs_v8bf, bw), acc, 0, 0, 0);
+          }
+        } else {
+          float av[16];
+          rs_get(X, av, lane);
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[(s * 32 + 16 * half + t) * RS_LDW + n], acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting later segments' LDS traffic
       }
 #pragma unroll
@@ -407,17 +451,21 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
 // data gradient: dsrc[s][p][:] = dm[p][:] @ W[:, 32s:32s+32], dm = dropout-masked dh
 template <int NS, bool DROP, bool OBF>      // OBF: gradients of sources 1.. are bf16 tensors (source 0 fp32)
 __global__ __launch_bounds__(256, 2) void rs_mlp_bwd_kernel(RsMlpArgs a) {
-  __shared__ float Ws[32 * (NS * 32 + 1)];       // [k = co][n], row stride 32*NS+1
-  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  // fp32: [k = co][n], row stride 32*NS+1.  OBF (bf16 MFMA): bf16 [n][k = co], row stride RS_LDXB
+  __shared__ __attribute__((aligned(16))) float Ws[OBF ? 16 * NS * RS_LDXB : 32 * (NS * 32 + 1)];
+  __shared__ __attribute__((aligned(16))) float Xs[4][OBF ? 16 * RS_LDXB : 32 * RS_LDX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, half = lane >> 5;
   constexpr int NT = 32 * NS, LW = NT + 1;
+  short* Wb = reinterpret_cast<short*>(Ws);
   for (int idx = tid; idx < 32 * NT; idx += 256) {
     const int co = idx / NT, c = idx - co * NT;
-    Ws[co * LW + c] = a.W[idx];
+    if (OBF) { __bf16 t = (__bf16)a.W[idx]; Wb[c * RS_LDXB + co] = __builtin_bit_cast(short, t); }
+    else Ws[co * LW + c] = a.W[idx];
   }
   __syncthreads();
   float* X = Xs[wave];
+  short* Xb = reinterpret_cast<short*>(Xs[wave]);
   const long P = a.P;
   const long NG = (P + 127) >> 7;
   const long nwaves = (long)gridDim.x * 4;
@@ -445,18 +493,30 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_bwd_kernel(RsMlpArgs a) {
           }
         }
       }
-      rs_put(X, ring[jb], lane);
+      if (OBF) rs_put_f2b(Xb, ring[jb], lane);
+      else rs_put(X, ring[jb], lane);
       rs_issue_block(ring[jb], srcr, gnext * 128 + jb * 32, lane_off);
       float av[16];
-      rs_get(X, av, lane);
+      rs_v8s ab[2];
+      if (OBF) rs_get_b(Xb, ab, lane);
+      else rs_get(X, av, lane);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (OBF) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[(16 * half + t) * LW + s * 32 + n], acc, 0, 0, 0);
+          for (int h = 0; h < 2; ++h) {
+            const rs_v8s bw = *reinterpret_cast<const rs_v8s*>(&Wb[(s * 32 + n) * RS_LDXB + 16 * h + 8 * half]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rs_v8bf, ab[h]),
+                                                          __builtin_bit_cast(rs_v8bf, bw), acc, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[(16 * half + t) * LW + s * 32 + n], acc, 0, 0, 0);
+        }
         if (OBF && s > 0) {
           const __amdgpu_buffer_rsrc_t o = rs_rsrc(a.out[s], P * 64);
 #pragma unroll

@@ -389,8 +389,9 @@ def test_gcn_mlp_bn(L, B, N, Tin, Tout, ns, drop, affine):
 
 @pytest.mark.parametrize('B,N,Tin,Tout,ns,drop', [(4, 20, 13, 12, 7, 0.0), (2, 67, 7, 7, 5, 0.3), (3, 37, 9, 7, 3, 0.0)])
 def test_gcn_mlp_bf16_storage(L, B, N, Tin, Tout, ns, drop):
-    """Sources 1.. and their gradients stored as bf16 tensors (bf16 mode of the engine): the loader widens,
-    the epilogue narrows; source 0 (the gated TCN output) stays fp32."""
+    """Throughput mode of the gcn mlp: sources 1.. and their gradients are bf16 tensors, and the contraction runs on
+    the bf16 MFMA (operands rounded to bf16, fp32 accumulate) -- tolerance 1e-2 of the output scale against fp32 math
+    on the same (bf16-rounded) sources; the weight gradient stays on the exact fp32 MFMA."""
     lib = L.load()
     G = N * B
     P = G * Tout
@@ -413,13 +414,13 @@ def test_gcn_mlp_bf16_storage(L, B, N, Tin, Tout, ns, drop):
            None, None, seed, thresh, dscale, L.ptr(h), L.ptr(partial), mask, L.stream())
     hc = h.cpu()
     if drop == 0.0:
-        close(hc, m + resc, what='h (bf16 sources)')
+        close(hc, m + resc, 1e-2, what='h (bf16 sources)')
         keep = torch.ones_like(m)
     else:
         from helpers import dropout_keep_mask
         kept = torch.from_numpy(dropout_keep_mask(seed, thresh, P * 32).reshape(P, 32))
         keep = kept.float() * dscale
-        close(hc, m * keep + resc, what='h (bf16 sources, dropout)')
+        close(hc, m * keep + resc, 1e-2, what='h (bf16 sources, dropout)')
         assert abs(1.0 - kept.float().mean().item() - drop) < 0.02
     dhh = rand(60, (P, 32))
     dm = dhh * keep
@@ -429,7 +430,7 @@ def test_gcn_mlp_bf16_storage(L, B, N, Tin, Tout, ns, drop):
     wsm = torch.empty(lib.mo_wgrad_ws_floats(32, 32 * ns, P), device='cuda')
     L.call('mo_gcn_mlp_bwd', L.ptr(dev(dhh)), L.ptr_array(sd), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P,
            seed, thresh, dscale, L.ptr(dW), L.ptr(db), L.ptr(wsm), None, 3, mask, mask, L.stream())
-    close(dsrcs[0], dcat[:, :32], what='dsrc0 (fp32)')
+    close(dsrcs[0], dcat[:, :32], 1e-2, what='dsrc0 (fp32 tensor, bf16 MFMA operands)')
     for s_ in range(1, ns):
         assert dsrcs[s_].dtype == torch.bfloat16
         close(dsrcs[s_].float(), dcat[:, 32 * s_:32 * (s_ + 1)], 8e-3, what=f'dsrc{s_} (bf16)')
