@@ -71,7 +71,9 @@ int mo_adp_bwd(const float* E1, const float* E2, const float* adp, float* dA, in
 int mo_tcn_pack_weights(const float* Wf, const float* Wg, int K, float* Wp, void* stream);
 int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
-               void* g_bf16 /* optional bf16 copy of g_out, may be NULL */, void* stream);
+               void* g_bf16 /* optional bf16 copy of g_out, may be NULL */,
+               int mfma_bf16 /* 1: contraction on the bf16 MFMA (operands rounded to bf16, fp32 accumulate:
+               the throughput mode); 0: exact fp32 MFMA */, void* stream);
 /* backward: recomputes the pre-activations; dpre (ws, G*Tout*64 floats) ; du[G*Tin][32] = conv^T(dpre)
  * (+ dres[(g,t-(Tin-Tout))] when dres != null: the residual path of graph_wavenet.py:247);
  * dWf,dWg (32,32,1,K), dbf,dbg (32). ws2: mo_wgrad_ws_floats(64, 32*K, G*Tout) floats. */
@@ -79,7 +81,8 @@ int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, cons
                const float* bf, const float* bg, int K, int dil, long G, int Tin, const float* dg,
                const float* dres, float* du, float* dWf, float* dWg, float* dbf, float* dbg,
                float* dpre_ws, float* ws2, int parts /* 1: dpre + data gradient, 2: weight/bias gradients
-               (needs dpre of part 1), 3: both */, void* stream);
+               (needs dpre of part 1), 3: both */, int mfma_bf16 /* as in mo_tcn_fwd (data path only; the
+               weight gradients stay fp32) */, void* stream);
 
 /* ---- diffusion graph convolution, node-axis products (nconv, graph_wavenet.py:64-66) -----------
  * Y[w][:] (+)= sum_e vals[e] * X[colidx[e]][:],  e in [rowptr[w], rowptr[w+1]);  rows of J floats.

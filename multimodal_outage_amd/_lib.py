@@ -29,9 +29,9 @@ SIGNATURES = {
     'mo_adp_fwd': (i32, [vp, vp, i32, i32, vp, vp, vp]),
     'mo_adp_bwd': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp]),
     'mo_tcn_pack_weights': (i32, [vp, vp, i32, vp, vp]),
-    'mo_tcn_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, vp]),
+    'mo_tcn_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, i32, vp]),
     'mo_tcn_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, vp,
-                         vp, vp, i32, vp]),
+                         vp, vp, i32, i32, vp]),
     'mo_spmm_csr': (i32, [vp, vp, vp, i32, vp, vp, i64, i32, i32, i32, vp]),
     'mo_adj_gemm': (i32, [vp, i32, vp, vp, i64, i32, vp]),
     'mo_adj_grad': (i32, [vp, vp, i32, i64, vp, i32, vp]),

@@ -586,23 +586,25 @@ static bool rs_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static bool rs_tcn_ok(int K, long G, int Tin, int Tout) {
   return K >= 1 && K <= 3 && Tin < 200 && Tout >= 1 && G * (long)Tin * 256 < 0xFFFFF000L;
 }
-static void rs_tcn_launch(int which, int K, const RsTcnArgs& a, long rows, hipStream_t st) {
+static void rs_tcn_launch(int which, int K, const RsTcnArgs& a, long rows, bool mf, hipStream_t st) {
   const long NG = (rows + 127) / 128;
   long nwg = (NG + 3) / 4;
   const long cap = (K <= 2 && which == 0) ? 768 : 512;      // workgroups per CU the kernel's registers allow
   if (nwg > cap) nwg = cap;
 #define RS_LAUNCH(KER) hipLaunchKernelGGL(KER, dim3((unsigned)nwg), dim3(256), 0, st, a)
-#define RS_CASE(k) if (K == k) { \
-    if (which == 0) RS_LAUNCH((rs_tcn_kernel<k, 0>)); else if (which == 1) RS_LAUNCH((rs_tcn_kernel<k, 1>)); \
-    else RS_LAUNCH((rs_tcn_du_kernel<k>)); return; }
+#define RS_CASE2(k, M) \
+    if (which == 0) RS_LAUNCH((rs_tcn_kernel<k, 0, M>)); else if (which == 1) RS_LAUNCH((rs_tcn_kernel<k, 1, M>)); \
+    else RS_LAUNCH((rs_tcn_du_kernel<k, M>));
+#define RS_CASE(k) if (K == k) { if (mf) { RS_CASE2(k, true) } else { RS_CASE2(k, false) } return; }
   RS_CASE(1) RS_CASE(2) RS_CASE(3)
 #undef RS_CASE
+#undef RS_CASE2
 #undef RS_LAUNCH
 }
 
 extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                           const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
-                          void* g_bf16, void* stream) {
+                          void* g_bf16, int mfma_bf16, void* stream) {
   const int Tout = Tin - dil * (K - 1);
   MO_CHECK_ARG(h_prev && Wp && bf && bg && g_out && K >= 1 && K <= MO_MAX_SEG && G > 0 && Tout > 0);
   MO_CHECK_ARG((scale == nullptr) == (shift == nullptr));
@@ -611,9 +613,10 @@ extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* 
     RsTcnArgs a = {};
     a.h_prev = h_prev; a.scale = scale; a.shift = shift; a.Wp = Wp; a.bf = bf; a.bg = bg;
     a.out = g_out; a.out_bf = (unsigned short*)g_bf16; a.G = G; a.Tin = Tin; a.Tout = Tout; a.dil = dil;
-    rs_tcn_launch(0, K, a, G * Tout, ST(stream));
+    rs_tcn_launch(0, K, a, G * Tout, mfma_bf16 != 0, ST(stream));
     return mo_launch_status();
   }
+  if (mfma_bf16) return MO_EUNSUPPORTED;
   MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
   MoEpi E; epi_init(E, g_out, 32);
   E.bias = bf; E.bias2 = bg; E.out_bf = (unsigned short*)g_bf16;
@@ -623,7 +626,7 @@ extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* 
 extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                           const float* bf, const float* bg, int K, int dil, long G, int Tin, const float* dg,
                           const float* dres, float* du, float* dWf, float* dWg, float* dbf, float* dbg,
-                          float* dpre_ws, float* ws2, int parts, void* stream) {
+                          float* dpre_ws, float* ws2, int parts, int mfma_bf16, void* stream) {
   const int Tout = Tin - dil * (K - 1);
   MO_CHECK_ARG(h_prev && Wp && bf && bg && dg && dWf && dWg && dbf && dbg && dpre_ws && ws2);
   MO_CHECK_ARG(K >= 1 && K <= MO_MAX_SEG && G > 0 && Tout > 0 && G * Tin < (1L << 31));
@@ -636,13 +639,14 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
     RsTcnArgs a = {};
     a.h_prev = h_prev; a.scale = scale; a.shift = shift; a.Wp = Wp; a.bf = bf; a.bg = bg;
     a.dg = dg; a.out = dpre_ws; a.G = G; a.Tin = Tin; a.Tout = Tout; a.dil = dil;
-    rs_tcn_launch(1, K, a, Pout, st);
+    rs_tcn_launch(1, K, a, Pout, mfma_bf16 != 0, st);
     if (du) {
       a.dpre = dpre_ws; a.dres = dres; a.du = du;
-      rs_tcn_launch(2, K, a, Pin, st);
+      rs_tcn_launch(2, K, a, Pin, mfma_bf16 != 0, st);
     }
   }
   // 1) recompute pre-activations, dpre[p][0:32] = d/d(filter pre-act), [32:64] = d/d(gate pre-act)
+  if (!rs && mfma_bf16) return MO_EUNSUPPORTED;
   if (!rs && (parts & 1)) {
     MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
     MoEpi E; epi_init(E, dpre_ws, 64);

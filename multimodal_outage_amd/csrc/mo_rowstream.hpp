@@ -581,19 +581,23 @@ __device__ __forceinline__ void rs_issue_tile(float4 (&v)[4], __amdgpu_buffer_rs
   for (int j = 0; j < 4; ++j) v[j] = rs_load4(r, off[j]);
 }
 
-template <int K, int MODE>
+template <int K, int MODE, bool MF>     // MF: bf16 MFMA (throughput mode) instead of the exact fp32 MFMA
 __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_kernel(RsTcnArgs a) {
   constexpr int LW = 65;
-  __shared__ float Ws[K * 32 * LW];                 // [tau*32 + ci][co']
-  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  constexpr int LWB = 32 * K + 8;                    // MF: bf16 [co' (64)][tau*32 + ci] rows
+  __shared__ __attribute__((aligned(16))) float Ws[MF ? 32 * LWB : K * 32 * LW];   // fp32: [tau*32 + ci][co']
+  __shared__ __attribute__((aligned(16))) float Xs[4][MF ? 16 * RS_LDXB : 32 * RS_LDX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, half = lane >> 5;
+  short* Wb = reinterpret_cast<short*>(Ws);
   for (int idx = tid; idx < K * 64 * 32; idx += 256) {
     const int tau = idx / 2048, rem = idx - tau * 2048, cop = rem >> 5, ci = rem & 31;
-    Ws[(tau * 32 + ci) * LW + cop] = a.Wp[idx];
+    if (MF) { __bf16 t = (__bf16)a.Wp[idx]; Wb[cop * LWB + tau * 32 + ci] = __builtin_bit_cast(short, t); }
+    else Ws[(tau * 32 + ci) * LW + cop] = a.Wp[idx];
   }
   __syncthreads();
   float* X = Xs[wave];
+  short* Xb = reinterpret_cast<short*>(Xs[wave]);
   const unsigned To = (unsigned)a.Tout, Ti = (unsigned)a.Tin;
   const long P = a.G * To;
   const long NG = (P + 127) >> 7;
@@ -649,18 +653,33 @@ __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_ker
           float4& v = ring[slot][j];
           v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
         }
-        rs_put(X, ring[slot], lane);
+        if (MF) rs_put_f2b(Xb, ring[slot], lane);
+        else rs_put(X, ring[slot], lane);
         {
           const int in = i + RS_R;
           issue_step(ring[slot], in < SPR ? gi : gnext, in % SPR);
         }
-        float av[16];
-        rs_get(X, av, lane);
+        if (MF) {
+          rs_v8s ab[2];
+          rs_get_b(Xb, ab, lane);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const float* wrow = &Ws[(tau * 32 + 16 * half + t) * LW];
-          accf = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wrow[n], accf, 0, 0, 0);
-          accg = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wrow[32 + n], accg, 0, 0, 0);
+          for (int h = 0; h < 2; ++h) {
+            const rs_v8s wf = *reinterpret_cast<const rs_v8s*>(&Wb[n * LWB + tau * 32 + 16 * h + 8 * half]);
+            const rs_v8s wg = *reinterpret_cast<const rs_v8s*>(&Wb[(32 + n) * LWB + tau * 32 + 16 * h + 8 * half]);
+            accf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rs_v8bf, ab[h]),
+                                                           __builtin_bit_cast(rs_v8bf, wf), accf, 0, 0, 0);
+            accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rs_v8bf, ab[h]),
+                                                           __builtin_bit_cast(rs_v8bf, wg), accg, 0, 0, 0);
+          }
+        } else {
+          float av[16];
+          rs_get(X, av, lane);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const float* wrow = &Ws[(tau * 32 + 16 * half + t) * LW];
+            accf = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wrow[n], accf, 0, 0, 0);
+            accg = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wrow[32 + n], accg, 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -683,15 +702,21 @@ __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_ker
 }
 
 // data gradient of the gated TCN: du[(g,t)][ci] = sum_tau dpre[(g, t - tau*d)][0:64] @ Wp[tau] (+ dres[(g, t - (Tin-Tout))])
-template <int K>
+template <int K, bool MF>
 __global__ __launch_bounds__(256, 2) void rs_tcn_du_kernel(RsTcnArgs a) {
-  __shared__ float Ws[K * 64 * RS_LDW];             // [tau*64 + co'][ci]
-  __shared__ __attribute__((aligned(16))) float Xs[4][32 * RS_LDX];
+  constexpr int LWB = 64 * K + 8;                   // MF: bf16 [ci (32)][tau*64 + co'] rows
+  __shared__ __attribute__((aligned(16))) float Ws[MF ? 16 * LWB : K * 64 * RS_LDW];   // fp32: [tau*64 + co'][ci]
+  __shared__ __attribute__((aligned(16))) float Xs[4][MF ? 16 * RS_LDXB : 32 * RS_LDX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, half = lane >> 5;
-  for (int idx = tid; idx < K * 64 * 32; idx += 256) Ws[(idx >> 5) * RS_LDW + (idx & 31)] = a.Wp[idx];
+  short* Wb = reinterpret_cast<short*>(Ws);
+  for (int idx = tid; idx < K * 64 * 32; idx += 256) {
+    if (MF) { __bf16 t = (__bf16)a.Wp[idx]; Wb[(idx & 31) * LWB + (idx >> 5)] = __builtin_bit_cast(short, t); }
+    else Ws[(idx >> 5) * RS_LDW + (idx & 31)] = a.Wp[idx];
+  }
   __syncthreads();
   float* X = Xs[wave];
+  short* Xb = reinterpret_cast<short*>(Xs[wave]);
   const unsigned To = (unsigned)a.Tout, Ti = (unsigned)a.Tin;
   const long P = a.G * Ti;                          // rows of du
   const long NG = (P + 127) >> 7;
@@ -739,17 +764,30 @@ __global__ __launch_bounds__(256, 2) void rs_tcn_du_kernel(RsTcnArgs a) {
 #pragma unroll
       for (int st = 0; st < SPB; ++st) {
         const int i = jb * SPB + st, slot = i % RS_R;
-        rs_put(X, ring[slot], lane);
+        if (MF) rs_put_f2b(Xb, ring[slot], lane);
+        else rs_put(X, ring[slot], lane);
         {
           const int in = i + RS_R;
           issue_step(ring[slot], in < SPR ? gi : gnext, in % SPR);
         }
-        float av[16];
-        rs_get(X, av, lane);
+        if (MF) {
+          rs_v8s ab[2];
+          rs_get_b(Xb, ab, lane);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[((st >> 1) * 64 + (st & 1) * 32 + 16 * half + t) * RS_LDW + n],
-                                                     acc, 0, 0, 0);
+          for (int h = 0; h < 2; ++h) {
+            const rs_v8s bw = *reinterpret_cast<const rs_v8s*>(
+                &Wb[n * LWB + (st >> 1) * 64 + (st & 1) * 32 + 16 * h + 8 * half]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rs_v8bf, ab[h]),
+                                                          __builtin_bit_cast(rs_v8bf, bw), acc, 0, 0, 0);
+          }
+        } else {
+          float av[16];
+          rs_get(X, av, lane);
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], Ws[((st >> 1) * 64 + (st & 1) * 32 + 16 * half + t) * RS_LDW + n],
+                                                       acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll

@@ -250,7 +250,7 @@ class GwnetFunction(torch.autograd.Function):
             g_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16) if use_bf else None
             L.call('mo_tcn_fwd', L.ptr(h), L.ptr(scale), L.ptr(shift), L.ptr(Wp),
                    L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, d, G, Tin,
-                   L.ptr(g), L.ptr(g_bf), st)
+                   L.ptr(g), L.ptr(g_bf), int(use_bf), st)
             srcs = [g]
             bf_saved = None
             if cfg.gcn:
@@ -329,6 +329,7 @@ class GwnetFunction(torch.autograd.Function):
         ctx.dims = (B, N, T, Tp, Tf, G)
         ctx.layers, ctx.x_int, ctx.adp, ctx.adpT, ctx.skip, ctx.r1 = layers, x_int, adp, adpT, skip, r1
         ctx.adp_bf = adp_bf
+        ctx.mfma_bf16 = int(use_bf)
         ctx.params = p
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -520,13 +521,13 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
                    L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, cfg.dil[i], G,
                    Tin, L.ptr(dg), L.ptr(dh), L.ptr(du), L.ptr(gWf), L.ptr(gWg), L.ptr(gbf), L.ptr(gbg),
-                   L.ptr(dpre), L.ptr(ws2_dummy), 1, st)
+                   L.ptr(dpre), L.ptr(ws2_dummy), 1, ctx.mfma_bf16, st)
 
             def _tcn_w(ly=ly, i=i, Tin=Tin, P=P, dg=dg, dpre=dpre, gWf=gWf, gWg=gWg, gbf=gbf, gbg=gbg):
                 L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
                        L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, cfg.dil[i], G,
                        Tin, L.ptr(dg), None, None, L.ptr(gWf), L.ptr(gWg), L.ptr(gbf), L.ptr(gbg),
-                       L.ptr(dpre), L.ptr(ws_for(64, 32 * K, P)), 2, L.stream())
+                       L.ptr(dpre), L.ptr(ws_for(64, 32 * K, P)), 2, 0, L.stream())
             lane.run(_tcn_w, reads=(dpre, dg))
             grads[f'filter_convs.{i}.weight'], grads[f'filter_convs.{i}.bias'] = gWf, gbf
             grads[f'gate_convs.{i}.weight'], grads[f'gate_convs.{i}.bias'] = gWg, gbg

@@ -181,7 +181,12 @@ def test_adp_fwd_bwd(L, N, R):
 @pytest.mark.parametrize('B,N,Tin,K,dil,affine', [(4, 20, 13, 2, 1, False), (4, 20, 12, 2, 2, True),
                                                   (1, 67, 7, 1, 1, True), (3, 37, 9, 3, 2, True),
                                                   (2, 50, 3, 2, 2, True)])
-def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine):
+@pytest.mark.parametrize('mf', [0, 1])
+def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine, mf):
+    # mf = 1: throughput mode, the data path contracts on the bf16 MFMA (operands rounded to bf16, fp32
+    # accumulate): stated tolerance 2e-2 of each result's scale; weight gradients stay on the fp32 MFMA but see
+    # the bf16-path pre-activation gradients
+    tol = 2e-2 if mf else 1e-4
     Tout = Tin - dil * (K - 1)
     G = N * B
     hprev = rand(20, (B, 32, N, Tin)).requires_grad_(True)
@@ -200,8 +205,8 @@ def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine):
     g_bf = torch.empty(G * Tout, 32, device='cuda', dtype=torch.bfloat16)
     scd, shd = (dev(sc), dev(sh)) if affine else (None, None)
     L.call('mo_tcn_fwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
-           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(g), L.ptr(g_bf), L.stream())
-    close(g, nbtc(g_ref), what='g')
+           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(g), L.ptr(g_bf), mf, L.stream())
+    close(g, nbtc(g_ref), tol, what='g')
     assert torch.equal(g_bf.cpu(), g.cpu().to(torch.bfloat16))          # fused bf16 copy == RNE of the fp32 result
 
     dg = rand(27, tuple(g_ref.shape))
@@ -221,12 +226,12 @@ def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine):
     ws2 = torch.empty(lib.mo_wgrad_ws_floats(64, 32 * K, G * Tout), device='cuda')
     L.call('mo_tcn_bwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
            L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(dev(nbtc(dg))), L.ptr(dev(nbtc(dres))), L.ptr(du),
-           L.ptr(dWf), L.ptr(dWg), L.ptr(dbf), L.ptr(dbg), L.ptr(dpre), L.ptr(ws2), 3, L.stream())
-    close(du, nbtc(du_ref), what='du')
-    close(dWf, Wf.grad, what='dWf')
-    close(dWg, Wg.grad, what='dWg')
-    close(dbf, bf.grad, what='dbf')
-    close(dbg, bg.grad, what='dbg')
+           L.ptr(dWf), L.ptr(dWg), L.ptr(dbf), L.ptr(dbg), L.ptr(dpre), L.ptr(ws2), 3, mf, L.stream())
+    close(du, nbtc(du_ref), tol, what='du')
+    close(dWf, Wf.grad, tol, what='dWf')
+    close(dWg, Wg.grad, tol, what='dWg')
+    close(dbf, bf.grad, tol, what='dbf')
+    close(dbg, bg.grad, tol, what='dbg')
 
 
 @pytest.mark.parametrize('N,J', [(67, 7 * 32), (20, 4 * 12 * 32), (301, 2 * 3 * 32), (3000, 32)])

@@ -15,8 +15,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--tout', type=int, default=12)
 ap.add_argument('--only', default='')
+ap.add_argument('--mf', type=int, default=0, help='1: bf16 MFMA in the TCN data path')
 a = ap.parse_args()
 lib = L.load()
+MF = a.mf
 N, B, Tout = 3000, a.batch, a.tout
 Tin = Tout + 1
 G = N * B
@@ -114,7 +116,7 @@ if want('tcn'):
     g = torch.empty(P, 32, device=dev)
     gbf = torch.empty(P, 32, device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: L.call('mo_tcn_fwd', L.ptr(res), L.ptr(sc), L.ptr(sh), L.ptr(Wp), L.ptr(b), L.ptr(b), K, d, G,
-                               Tin, L.ptr(g), L.ptr(gbf), st))
+                               Tin, L.ptr(g), L.ptr(gbf), MF, st))
     report('tcn_fwd (h -> g, g_bf16)', ms, int(row * (Tin / Tout + 1.5)))
     du = torch.empty(G * Tin, 32, device=dev)
     dpre = torch.empty(P * 64, device=dev)
@@ -123,11 +125,11 @@ if want('tcn'):
     gb = [torch.empty(32, device=dev) for _ in range(2)]
     ms = timeit(lambda: L.call('mo_tcn_bwd', L.ptr(res), L.ptr(sc), L.ptr(sh), L.ptr(Wp), L.ptr(b), L.ptr(b), K, d, G,
                                Tin, L.ptr(dh), L.ptr(dsrcs[0]), L.ptr(du), L.ptr(gW[0]), L.ptr(gW[1]), L.ptr(gb[0]),
-                               L.ptr(gb[1]), L.ptr(dpre), L.ptr(ws2), 1, st))
+                               L.ptr(gb[1]), L.ptr(dpre), L.ptr(ws2), 1, MF, st))
     report('tcn_bwd data (dg,h -> dpre,du)', ms, int(row * (Tin / Tout * 2 + 1 + 2 + 1)))
     ms = timeit(lambda: L.call('mo_tcn_bwd', L.ptr(res), L.ptr(sc), L.ptr(sh), L.ptr(Wp), L.ptr(b), L.ptr(b), K, d, G,
                                Tin, L.ptr(dh), L.ptr(dsrcs[0]), L.ptr(du), L.ptr(gW[0]), L.ptr(gW[1]), L.ptr(gb[0]),
-                               L.ptr(gb[1]), L.ptr(dpre), L.ptr(ws2), 2, st))
+                               L.ptr(gb[1]), L.ptr(dpre), L.ptr(ws2), 2, MF, st))
     report('tcn_bwd wgrad (dpre, h)', ms, int(row * (2 + Tin / Tout)))
 
 if want('bn'):
