@@ -351,8 +351,13 @@ static bool rsw_ok(const MoOperand& A, const MoOperand& B, long P, int M, int N)
 }
 template <int MA, int NB>
 static void rsw_launch2(const MoOperand& A, const MoOperand& B, float* slab, float* cs, long P, int post_b, int nwg,
-                        hipStream_t st) {
-  const size_t lds = (size_t)MA * NB * 16 * 64 * 2 * sizeof(float);
+                        bool mf, hipStream_t st) {
+  size_t lds = (size_t)MA * NB * 16 * 64 * 2 * sizeof(float);
+  if (mf && lds < 4 * 32 * RS_LDXB * sizeof(short)) lds = 4 * 32 * RS_LDXB * sizeof(short);   // the waves' LDS tiles
+  if (mf) {      // bf16 MFMA form (throughput mode, bf16-stored sources: the gcn mlp): workgroups walk 128-row runs
+    hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, false, true>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
+    return;
+  }
   if (NB > 1 && B.seg[1].bf16)       // bf16-stored sources 1.. (the gcn mlp of the throughput mode; unmapped)
     hipLaunchKernelGGL((rs_wgrad_kernel<MA, NB, false, true>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
   else if (B.seg[0].To)
@@ -361,17 +366,20 @@ static void rsw_launch2(const MoOperand& A, const MoOperand& B, float* slab, flo
     hipLaunchKernelGGL((rs_wgrad_kernel<MA, NB, false>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
 }
 static void rsw_launch(int MA, int NB, const MoOperand& A, const MoOperand& B, float* slab, float* cs, long P,
-                       int post_b, int nwg, hipStream_t st) {
-#define RSW_CASE(a, b) if (MA == a && NB == b) return rsw_launch2<a, b>(A, B, slab, cs, P, post_b, nwg, st);
+                       int post_b, int nwg, bool mf, hipStream_t st) {
+#define RSW_CASE(a, b) if (MA == a && NB == b) return rsw_launch2<a, b>(A, B, slab, cs, P, post_b, nwg, mf, st);
   RSW_CASE(1, 1) RSW_CASE(1, 2) RSW_CASE(1, 3) RSW_CASE(1, 4) RSW_CASE(1, 5) RSW_CASE(1, 6) RSW_CASE(1, 7)
   RSW_CASE(1, 8) RSW_CASE(2, 1) RSW_CASE(2, 2) RSW_CASE(2, 3) RSW_CASE(2, 4) RSW_CASE(8, 1)
 #undef RSW_CASE
 }
 
 static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int N, float* ws, float* dW, float* db,
-                     hipStream_t st, bool* db_done = nullptr, int* nslab = nullptr) {
+                     hipStream_t st, bool* db_done = nullptr, int* nslab = nullptr, bool mf = false) {
   if (rsw_ok(A, Bo, P, M, N)) {
-    const int crows = 2 * rsw_u(M / 32, N / 32);
+    // (the mapped / fp32-source instances of the bf16 form ran out of registers: tcn and skip stay on the fp32 form)
+    mf = mf && Bo.nseg > 1 && Bo.seg[1].bf16 && P * (long)M * 4 < 0xFFFFF000L && (((uintptr_t)A.seg[0].ptr) & 15) == 0;
+    for (int j = 0; j < Bo.nseg; ++j) mf = mf && (((uintptr_t)Bo.seg[j].ptr) & 15) == 0;
+    const int crows = mf ? 128 / 4 : 2 * rsw_u(M / 32, N / 32);     // rows per wave-chunk (bf16 form: 4 waves x 128-row runs)
     const long nchunk = (P + crows - 1) / crows;
     long nwg = (nchunk + 3) / 4;
     const long cap = 512;                                      // 2 workgroups per CU (register budget)
@@ -380,7 +388,7 @@ static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int
     int post_b = 0;
     for (int j = 0; j < Bo.nseg; ++j) if (Bo.seg[j].scale) post_b |= 1;
     if (Bo.seg[0].relu) post_b |= 2;
-    rsw_launch(M / 32, N / 32, A, Bo, ws, db ? cs : nullptr, P, post_b, (int)nwg, st);
+    rsw_launch(M / 32, N / 32, A, Bo, ws, db ? cs : nullptr, P, post_b, (int)nwg, mf, st);
     if (dW) {
       long n = (long)M * N;
       hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(n), dim3(256), 0, st, ws, n, (int)nwg, dW, n);
@@ -682,7 +690,7 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
     float* db64 = ws2 + mo_wgrad_ws_floats(64, 32 * K, Pout) - 64;
     bool done = false;
     int nsplit = 0;
-    rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, db64, st, &done, &nsplit);
+    rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, db64, st, &done, &nsplit, mfma_bf16 != 0);
     if (rc) return rc;
     hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(mo_cdiv(64 * 32 * K, 32)), dim3(256), 0, st, ws2,
                        (long)64 * 32 * K, nsplit, K, dWf, dWg);
@@ -1113,7 +1121,7 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
   for (int s = 0; s < ns; ++s) { seg_init(B2.seg[s], srcs[s], 32); B2.seg[s].bf16 = (src_bf16_mask >> s) & 1; }
   if (src_bf16_mask && !rsw_ok(A2, B2, P, 32, 32 * ns)) return MO_EUNSUPPORTED;
   bool done = false;
-  rc = wgrad_run(A2, B2, P, 32, 32 * ns, ws, dW, db, st, &done);
+  rc = wgrad_run(A2, B2, P, 32, 32 * ns, ws, dW, db, st, &done, nullptr, src_bf16_mask != 0);
   if (rc) return rc;
   if (done) return MO_OK;
   // bias: db[co] = sum_p dm[p][co]  (dropout mask applies) -> reuse the GEMM with a ones column is

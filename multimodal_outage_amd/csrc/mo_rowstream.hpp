@@ -799,3 +799,216 @@ __global__ __launch_bounds__(256, 2) void rs_tcn_du_kernel(RsTcnArgs a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients on the bf16 MFMA (throughput mode).  The contraction index is the ROW, so the operands are
+// needed k-major: every 32-row tile (coalesced 16-byte loads, fp32 tiles rounded to bf16 on the way) goes through
+// the wave's LDS tile and comes back TRANSPOSED by ds_read_b64_tr_b16 -- two MFMAs per 32 rows and 32x32 block
+// instead of sixteen fp32 ones, and eight times fewer load instructions than the dword-per-lane fp32 form.
+// Same slab / column-sum contract as rs_wgrad_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef short rs_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) rs_v4s* rs_lds_v4s_ptr;
+// f[s]: lane (column lane&31) gets rows k = 16s + 8*(lane>>5) + 0..7 of the [32][32] bf16 tile
+__device__ __forceinline__ void rs_get_tr(const short* Xb, rs_v8s (&f)[2], int lane) {
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int kr = 16 * s + 8 * (tg >> 1) + tq, nc = 16 * (tg & 1) + 4 * tp;
+    const rs_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rs_lds_v4s_ptr)&Xb[kr * RS_LDXB + nc]);
+    const rs_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rs_lds_v4s_ptr)&Xb[(kr + 4) * RS_LDXB + nc]);
+    f[s] = (rs_v8s){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+template <int MA, int NB, bool MAPPED, bool BBF>
+__global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOperand B, float* __restrict__ slab,
+                                                            float* __restrict__ cs, long P, int post_b) {
+  extern __shared__ float rs_sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, half = lane >> 5;
+  short* Xb = reinterpret_cast<short*>(rs_sm) + wave * (32 * RS_LDXB);
+  const long NG = (P + 127) >> 7;
+  const long nwaves = (long)gridDim.x * 4;
+  const long w = (long)wave * gridDim.x + blockIdx.x;
+  constexpr int LDA = 32 * MA, S = MA + NB, SPR = 4 * S, RS_R = 4;
+
+  f32x16 acc[MA][NB];
+#pragma unroll
+  for (int i = 0; i < MA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 csum[MA];
+#pragma unroll
+  for (int i = 0; i < MA; ++i) csum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const unsigned To = MAPPED ? (unsigned)B.seg[0].To : 1u;
+  const unsigned inv16 = 65536u / To + 1u;
+  const __amdgpu_buffer_rsrc_t ar = rs_rsrc(A.seg[0].ptr, P * LDA * 4);
+  __amdgpu_buffer_rsrc_t br[NB];
+  float4 bsc[NB], bsh[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const long rows = MAPPED ? (P / To) * B.seg[j].Ti : P;
+    br[j] = rs_rsrc(B.seg[j].ptr, rows * ((BBF && j > 0) ? 64 : 128));
+    bsc[j] = make_float4(1.f, 1.f, 1.f, 1.f); bsh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (B.seg[j].scale) {
+      bsc[j] = *reinterpret_cast<const float4*>(B.seg[j].scale + 4 * (lane & 7));
+      bsh[j] = *reinterpret_cast<const float4*>(B.seg[j].shift + 4 * (lane & 7));
+    }
+  }
+  const unsigned lane_off = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16);
+  const unsigned lane_off_bf = (unsigned)((lane >> 2) * 64 + (lane & 3) * 16);
+  const unsigned lane_off_a = (unsigned)((lane >> 3) * (LDA * 4) + (lane & 7) * 16);
+  const uint32_t dseed = A.seg[0].drop_seed, dthresh = A.seg[0].drop_thresh;
+  const float dscale = A.seg[0].drop_scale;
+
+  float4 ring[RS_R][4];
+  auto issue_step = [&](float4 (&dst)[4], long gi, int i) {      // step i of run gi: block i / S, operand tile i % S
+    const long row0 = gi * 128 + (i / S) * 32;
+    const int t = i % S;
+    if (t < MA) {
+      const unsigned base = (unsigned)(row0 * (LDA * 4)) + lane_off_a + 128u * t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[j] = rs_load4(ar, base + (unsigned)(8 * LDA * 4) * j);
+    } else {
+      const int j = t - MA;
+      if (MAPPED) {
+        unsigned off[4];
+        rs_tile_offsets(off, row0, P, To, (unsigned)B.seg[j].Ti, inv16, B.seg[j].off, 128u,
+                        (unsigned)((lane & 7) * 16), lane);
+        rs_issue_tile(dst, br[j], off);
+      } else if (BBF && j > 0) {
+        rs_issue_block_bf(dst, br[j], row0, lane_off_bf);
+      } else {
+        rs_issue_block(dst, br[j], row0, lane_off);
+      }
+    }
+  };
+
+  if (w < NG) {
+#pragma unroll
+    for (int i = 0; i < RS_R; ++i) issue_step(ring[i], w, i);
+    for (long gi = w; gi < NG; gi += nwaves) {
+      const long gnext = (gi + nwaves < NG) ? gi + nwaves : gi;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const long m0 = gi * 128 + jb * 32;
+        rs_v8s af[MA][2];
+#pragma unroll
+        for (int ma = 0; ma < MA; ++ma) {
+          const int i = jb * S + ma, slot = i % RS_R;
+          // a tile: regenerated dropout mask, column sums (the bias gradient) from the fp32 values
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float* vp = &ring[slot][j].x;
+            if (dthresh) {
+              const uint32_t e = (uint32_t)((m0 + 8 * j + (lane >> 3)) * LDA + ma * 32 + 4 * (lane & 7));
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const uint32_t h = mo_hash32(dseed, e + q);
+                vp[q] = (h >= dthresh) ? vp[q] * dscale : 0.f;
+              }
+            }
+            csum[ma].x += vp[0]; csum[ma].y += vp[1]; csum[ma].z += vp[2]; csum[ma].w += vp[3];
+          }
+          rs_put_f2b(Xb, ring[slot], lane);
+          issue_step(ring[slot], (i + RS_R) < SPR ? gi : gnext, (i + RS_R) % SPR);
+          rs_get_tr(Xb, af[ma], lane);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int i = jb * S + MA + j, slot = i % RS_R;
+          if (BBF && j > 0) {
+            rs_put_b2b(Xb, ring[slot], lane);
+          } else {
+            if (post_b) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float4& v = ring[slot][q];
+                v.x = v.x * bsc[j].x + bsh[j].x; v.y = v.y * bsc[j].y + bsh[j].y;
+                v.z = v.z * bsc[j].z + bsh[j].z; v.w = v.w * bsc[j].w + bsh[j].w;
+                if (post_b & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              }
+            }
+            rs_put_f2b(Xb, ring[slot], lane);
+          }
+          issue_step(ring[slot], (i + RS_R) < SPR ? gi : gnext, (i + RS_R) % SPR);
+          rs_v8s bfr[2];
+          rs_get_tr(Xb, bfr, lane);
+#pragma unroll
+          for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              acc[ma][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rs_v8bf, af[ma][s]),
+                                                                   __builtin_bit_cast(rs_v8bf, bfr[s]), acc[ma][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+
+  // ---- workgroup reduction of the four waves' partial tiles through LDS, then one slab per workgroup
+  __syncthreads();                                   // the wave tiles at the start of rs_sm are done with
+  constexpr int TILE = MA * NB * 16 * 64;
+  float* buf0 = rs_sm;
+  float* buf1 = rs_sm + TILE;
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((i * NB + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * NB + j) * 16 + r) * 64 + lane];
+  };
+  if (wave == 2) put(buf0);
+  if (wave == 3) put(buf1);
+  __syncthreads();
+  if (wave == 0) add(buf0);
+  if (wave == 1) add(buf1);
+  __syncthreads();
+  if (wave == 1) put(buf0);
+  __syncthreads();
+  if (wave == 0) {
+    add(buf0);
+    float* out = slab + (long)blockIdx.x * (32 * MA) * (32 * NB);
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          out[(long)m * (32 * NB) + j * 32 + c] = acc[i][j][r];
+        }
+  }
+  if (cs) {
+    // column sums: lane holds columns 4*(lane&7)..+3 summed over its rows; fold the 8 row groups and 4 waves
+    __syncthreads();
+    float4* cbuf = reinterpret_cast<float4*>(rs_sm);              // [wave][MA][64]
+#pragma unroll
+    for (int i = 0; i < MA; ++i) cbuf[(wave * MA + i) * 64 + lane] = csum[i];
+    __syncthreads();
+    if (tid < 32 * MA) {
+      const int i = tid >> 5, col = tid & 31;
+      float s = 0.f;
+      for (int q = 0; q < 4; ++q)
+        for (int gq = 0; gq < 8; ++gq) {
+          const float4 v = cbuf[(q * MA + i) * 64 + gq * 8 + (col >> 2)];
+          s += (col & 3) == 0 ? v.x : (col & 3) == 1 ? v.y : (col & 3) == 2 ? v.z : v.w;
+        }
+      cs[(long)blockIdx.x * (32 * MA) + tid] = s;
+    }
+  }
+}

@@ -167,6 +167,8 @@ class _WgradLane:
         self.side = _side_stream((dev, 'wgrad')) if enabled else None
 
     def run(self, fn, reads=()):
+        if 'wgrad' in _SKIP:
+            return
         if self.side is None:
             fn()
             return
@@ -527,7 +529,7 @@ class GwnetFunction(torch.autograd.Function):
                 L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
                        L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, cfg.dil[i], G,
                        Tin, L.ptr(dg), None, None, L.ptr(gWf), L.ptr(gWg), L.ptr(gbf), L.ptr(gbg),
-                       L.ptr(dpre), L.ptr(ws_for(64, 32 * K, P)), 2, 0, L.stream())
+                       L.ptr(dpre), L.ptr(ws_for(64, 32 * K, P)), 2, ctx.mfma_bf16, L.stream())
             lane.run(_tcn_w, reads=(dpre, dg))
             grads[f'filter_convs.{i}.weight'], grads[f'filter_convs.{i}.bias'] = gWf, gbf
             grads[f'gate_convs.{i}.weight'], grads[f'gate_convs.{i}.bias'] = gWg, gbg

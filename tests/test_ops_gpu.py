@@ -396,7 +396,7 @@ def test_gcn_mlp_bn(L, B, N, Tin, Tout, ns, drop, affine):
 def test_gcn_mlp_bf16_storage(L, B, N, Tin, Tout, ns, drop):
     """Throughput mode of the gcn mlp: sources 1.. and their gradients are bf16 tensors, and the contraction runs on
     the bf16 MFMA (operands rounded to bf16, fp32 accumulate) -- tolerance 1e-2 of the output scale against fp32 math
-    on the same (bf16-rounded) sources; the weight gradient stays on the exact fp32 MFMA."""
+    on the same (bf16-rounded) sources (the bias gradient is summed from the fp32 values)."""
     lib = L.load()
     G = N * B
     P = G * Tout
@@ -439,7 +439,7 @@ def test_gcn_mlp_bf16_storage(L, B, N, Tin, Tout, ns, drop):
     for s_ in range(1, ns):
         assert dsrcs[s_].dtype == torch.bfloat16
         close(dsrcs[s_].float(), dcat[:, 32 * s_:32 * (s_ + 1)], 8e-3, what=f'dsrc{s_} (bf16)')
-    close(dW, dm.t() @ cat, what='dWm (bf16 sources)')
+    close(dW, dm.t() @ cat, 1e-2, what='dWm (bf16 sources, bf16 MFMA)')
     close(db, dm.sum(0), what='dbm')
 
 def test_metrics_and_grad(L):
