@@ -281,7 +281,7 @@ class GwnetFunction(torch.autograd.Function):
                 for s in statics:
                     x1 = torch.empty((P, 32), device=dev, dtype=idt)
                     x2 = torch.empty((P, 32), device=dev, dtype=idt)
-                    _spmm(s.fwd, N, g, x1, J, 0)
+                    _spmm(s.fwd, N, g_bf if use_bf else g, x1, J, 0)     # throughput mode gathers the bf16 copy
                     _spmm(s.fwd, N, x1, x2, J, 0)
                     srcs += [x1, x2]
                 srcs += dense_out
