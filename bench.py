@@ -104,7 +104,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=64, help='windows per GPU per step (weak scaling)')
+    ap.add_argument('--batch', type=int, default=128, help='windows per GPU per step (weak scaling)')
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16',
                     help='operand type of the dense adaptive-adjacency products (fp32 accumulate either way)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to rehearse "

@@ -354,8 +354,11 @@ static void rsw_launch2(const MoOperand& A, const MoOperand& B, float* slab, flo
                         bool mf, hipStream_t st) {
   size_t lds = (size_t)MA * NB * 16 * 64 * 2 * sizeof(float);
   if (mf && lds < 4 * 32 * RS_LDXB * sizeof(short)) lds = 4 * 32 * RS_LDXB * sizeof(short);   // the waves' LDS tiles
-  if (mf) {      // bf16 MFMA form (throughput mode, bf16-stored sources: the gcn mlp): workgroups walk 128-row runs
-    hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, false, true>), dim3(nwg), dim3(256), lds, st, A, B, slab, cs, P, post_b);
+  if (mf) {      // bf16 MFMA form (throughput mode): workgroups walk 128-row runs
+    const bool bbf = NB > 1 && B.seg[1].bf16;
+    dim3 g(nwg), b(256);
+    if (bbf) hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, false, true>), g, b, lds, st, A, B, slab, cs, P, post_b);
+    else hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, true, false>), g, b, lds, st, A, B, slab, cs, P, post_b);
     return;
   }
   if (NB > 1 && B.seg[1].bf16)       // bf16-stored sources 1.. (the gcn mlp of the throughput mode; unmapped)
@@ -377,7 +380,8 @@ static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int
                      hipStream_t st, bool* db_done = nullptr, int* nslab = nullptr, bool mf = false) {
   if (rsw_ok(A, Bo, P, M, N)) {
     // (the mapped / fp32-source instances of the bf16 form ran out of registers: tcn and skip stay on the fp32 form)
-    mf = mf && Bo.nseg > 1 && Bo.seg[1].bf16 && P * (long)M * 4 < 0xFFFFF000L && (((uintptr_t)A.seg[0].ptr) & 15) == 0;
+    mf = mf && ((Bo.nseg > 1 && Bo.seg[1].bf16) || (Bo.seg[0].To != 0 && M == 64)) && P * (long)M * 4 < 0xFFFFF000L &&
+         (((uintptr_t)A.seg[0].ptr) & 15) == 0;      // the gcn mlp and the TCN instances
     for (int j = 0; j < Bo.nseg; ++j) mf = mf && (((uintptr_t)Bo.seg[j].ptr) & 15) == 0;
     const int crows = mf ? 128 / 4 : 2 * rsw_u(M / 32, N / 32);     // rows per wave-chunk (bf16 form: 4 waves x 128-row runs)
     const long nchunk = (P + crows - 1) / crows;

@@ -912,9 +912,20 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
                 vp[q] = (h >= dthresh) ? vp[q] * dscale : 0.f;
               }
             }
-            csum[ma].x += vp[0]; csum[ma].y += vp[1]; csum[ma].z += vp[2]; csum[ma].w += vp[3];
           }
           rs_put_f2b(Xb, ring[slot], lane);
+          // Column sums on the VALU through inline asm: written as plain `csum += v` the compiler re-associated the
+          // sums into many partials (~60 VGPRs in this kernel).  hipcc does NOT insert the vmcnt wait for a load
+          // result that only an inline-asm operand consumes, so the adds sit BEHIND the tile's LDS stores (the
+          // "memory" clobber keeps them there): the conversions feeding those stores have already waited.
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].x) : "v"(ring[slot][j].x) : "memory");
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].y) : "v"(ring[slot][j].y) : "memory");
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].z) : "v"(ring[slot][j].z) : "memory");
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].w) : "v"(ring[slot][j].w) : "memory");
+          }
           issue_step(ring[slot], (i + RS_R) < SPR ? gi : gnext, (i + RS_R) % SPR);
           rs_get_tr(Xb, af[ma], lane);
           __builtin_amdgcn_sched_barrier(0);
