@@ -99,6 +99,56 @@ def cpu_baseline(supports, max_steps=5, batch=4, budget_s=25.0):
                       f"dropout 0.3) after 1 warm-up step; {dt:.1f} s"}
 
 
+def unet_leg(world, dev, steps=5, warmup=2, batch=1, horizon=2, cin=13, size=256):
+    """Secondary metric of BASELINE.json ("+ UNet tiles/sec"): Modified_UNET training step (forward + MSE/metrics +
+    backward + all-reduce + Adam) on synthetic (B,67,H,13,256,256) GOES-style tiles (config 3), fp32, batch-sharded
+    like the gwnet leg.  Returns the object printed under "unet"."""
+    from multimodal_outage_amd.models.unet import Modified_UNET
+    from multimodal_outage_amd.lit import mse_and_metrics
+    from multimodal_outage_amd.trainer import FlatTrainer
+    torch.manual_seed(42)
+    m = Modified_UNET('gwnet', horizon, input_channels=cin, output_channels=cin, image_dimension=size).to(dev).train()
+    tr = FlatTrainer(m)
+    g = torch.Generator().manual_seed(2000 + int(os.environ.get('RANK', '0')))
+    x = torch.randn(batch, 67, horizon, cin, size, size, generator=g).to(dev)
+    y = torch.randn(batch, 67, horizon, cin, size, size, generator=g).to(dev)
+    td = torch.randn(batch, 67, horizon, 64, generator=g).to(dev)
+
+    def step():
+        tr.zero_grad()
+        loss, _, _, _ = mse_and_metrics(m(x, td), y)
+        loss.backward()
+        tr.allreduce()
+        tr.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tiles = batch * 67 * horizon
+    return {"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(world * tiles * steps / dt, 1), "unit": "tiles/s",
+            "ms_per_step": round(dt / steps * 1e3, 2), "tiles_per_step_per_gpu": tiles, "steps": steps, "warmup": warmup,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Modified_UNET fwd+MSE+bwd+Adam on ({batch},67,{horizon},{cin},{size},{size}) tiles",
+                       "tile": f"{cin}x{size}x{size}", "counties": 67, "horizon": horizon, "parallelism": f"dp{world}"},
+            "loss": round(float(loss.detach()), 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -110,6 +160,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to rehearse "
                     "the multi-rank control flow on a one-GPU box)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-unet', action='store_true', help='skip the secondary UNet tiles/s leg')
     ap.add_argument('--cpu-steps', type=int, default=5)
     args = ap.parse_args()
 
@@ -160,6 +211,8 @@ def main():
         out.backward(dy)
         trainer.allreduce()
         trainer.step()
+
+    out_keep = None
 
     def sync():
         torch.cuda.synchronize()
@@ -238,6 +291,11 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "nodes": N_NODES, "seq_len": T_IN,
                        "parallelism": f"dp{world}"},
             "loss": round(loss, 6), "roofline": roofline, "roofline_hbm_block": hbm_block}
+    if not args.no_unet:
+        # free the gwnet leg's tensors first, then the secondary leg (every rank takes part: it all-reduces)
+        del model, trainer, x, y, dy, out_keep
+        torch.cuda.empty_cache()
+        line["unet"] = unet_leg(world, dev)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             print("[bench] gpu: " + json.dumps({k: line[k] for k in ("value", "ms_per_step", "loss")}), file=sys.stderr, flush=True)

@@ -1,0 +1,198 @@
+// Direct 3x3 convolutions for the UNet's thin layers (unet.py:44-48: 13->4->4 at 256^2, 4->8->8 at 128^2, ...).
+// At 4..32 channels these are not contractions worth an im2col GEMM: the implicit-GEMM form spent its time on
+// per-element index arithmetic.  Here a workgroup owns a spatial tile of one image: the activated input halo
+// tile (folded BatchNorm affine + ReLU applied on the way in, zero padding after activation) is staged in LDS
+// eight channels at a time, each thread keeps 4 neighbouring pixels x all output channels in registers and
+// walks the 9 taps with the weights read as LDS broadcasts.
+#pragma once
+#include "mo_common.h"
+
+#define UD_CK 8          // input channels per LDS stage
+
+struct UdConvArgs {
+  const float* in0; const float* sc0; const float* sh0; long is0; int C0, relu0;
+  const float* in1; const float* sc1; const float* sh1; long is1; int C1, relu1;
+  const float* W;          // (Co, C0+C1, 3, 3)
+  float* out; long os;
+  int Co, H, Wd, gsize;
+};
+
+// activated value of channel c (of the concat) at (y, x) of image img; zero outside the image
+__device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, int c, int y, int x) {
+  if ((unsigned)y >= (unsigned)a.H || (unsigned)x >= (unsigned)a.Wd) return 0.f;
+  const bool first = c < a.C0;
+  const int cc = first ? c : c - a.C0;
+  const float* base = first ? a.in0 : a.in1;
+  const long is = first ? a.is0 : a.is1;
+  float v = base[img * is + ((long)cc * a.H + y) * a.Wd + x];
+  const float* sc = first ? a.sc0 : a.sc1;
+  if (sc) {
+    const float* sh = first ? a.sh0 : a.sh1;
+    const int C = first ? a.C0 : a.C1;
+    const long gi = (img / a.gsize) * C + cc;
+    v = v * sc[gi] + sh[gi];
+  }
+  if (first ? a.relu0 : a.relu1) v = fmaxf(v, 0.f);
+  return v;
+}
+
+// TH x TW output pixels per workgroup (256 threads, 4 pixels along x each): (16,64) or (32,32)
+template <int CO, int TH, int TW>
+__global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
+  constexpr int LDT = TW + 4;                                   // halo row stride (16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) float tile[UD_CK][TH + 2][LDT];
+  __shared__ __attribute__((aligned(16))) float wsm[UD_CK][9][CO];
+  const int tid = threadIdx.x;
+  constexpr int GX = TW / 4;
+  const int tx4 = (tid % GX) * 4, ty = tid / GX;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const long img = blockIdx.z;
+  const int Ci = a.C0 + a.C1;
+  float acc[CO][4];
+#pragma unroll
+  for (int co = 0; co < CO; ++co)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+
+  for (int c0 = 0; c0 < Ci; c0 += UD_CK) {
+    const int nc = min(UD_CK, Ci - c0);
+    __syncthreads();                                            // previous stage fully consumed
+    // halo tile: columns x0-1 .. x0+TW (TW+2 values), rows y0-1 .. y0+TH
+    for (int idx = tid; idx < nc * (TH + 2) * (TW + 2); idx += 256) {
+      const int c = idx / ((TH + 2) * (TW + 2)), r = idx - c * ((TH + 2) * (TW + 2));
+      const int yy = r / (TW + 2), xx = r - yy * (TW + 2);
+      tile[c][yy][xx] = ud_act(a, img, c0 + c, y0 + yy - 1, x0 + xx - 1);
+    }
+    for (int idx = tid; idx < nc * 9 * CO; idx += 256) {
+      const int c = idx / (9 * CO), r = idx - c * (9 * CO), tap = r / CO, co = r - tap * CO;
+      wsm[c][tap][co] = (co < a.Co) ? a.W[((long)co * Ci + c0 + c) * 9 + tap] : 0.f;
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float seg[6];
+        const float* row = &tile[c][ty + ky][tx4];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) seg[q] = row[q];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+          for (int co = 0; co < CO; ++co) {
+            const float w = wsm[c][ky * 3 + kx][co];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[co][p] += w * seg[p + kx];
+          }
+        }
+      }
+    }
+  }
+  const int y = y0 + ty, x = x0 + tx4;
+  if (y < a.H && x < a.Wd) {                                     // Wd % 4 == 0: a quad is all in or all out
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+      if (co < a.Co)
+        *reinterpret_cast<float4*>(&a.out[img * a.os + ((long)co * a.H + y) * a.Wd + x]) =
+            make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the thin 3x3 convs: dW[co][ci][tap] = sum_{img,y,x} dy[img][co][y][x] * act(in)[img][ci][y+ky-1][x+kx-1].
+// A workgroup owns one spatial tile position, a range of images, 4 output channels and 4 input channels: every
+// thread keeps the 4 x 4 x 9 partial sums of its own pixel quads in registers across the whole image range
+// (dy quads straight from global, the activated input halo through LDS), and the 256 threads are folded once at
+// the end (wave shuffles, then LDS).  One slab row per (tile, image range); uslab_reduce_kernel sums the rows.
+// ------------------------------------------------------------------------------------------------
+#define UD_WC 4          // channels per operand per workgroup
+
+struct UdWgradArgs {
+  const float* dy; long dys;
+  const float* in0; const float* sc0; const float* sh0; long is0; int C0, relu0;
+  const float* in1; const float* sc1; const float* sh1; long is1; int C1, relu1;
+  float* slab;             // [nz][Co*Ci*9]
+  int Co, H, Wd, gsize;
+  long n_img; int img_per_wg, n_cichunk;
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
+  constexpr int LDT = TW + 4;
+  __shared__ __attribute__((aligned(16))) float tile[UD_WC][TH + 2][LDT];
+  __shared__ float red[4][UD_WC * UD_WC * 9];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int GX = TW / 4;
+  const int tx4 = (tid % GX) * 4, ty = tid / GX;
+  const int tiles_x = (a.Wd + TW - 1) / TW;
+  const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
+  const long img0 = (long)blockIdx.y * a.img_per_wg;
+  const long img1 = min(img0 + a.img_per_wg, a.n_img);
+  const int ci0 = (blockIdx.z % a.n_cichunk) * UD_WC, co0 = (blockIdx.z / a.n_cichunk) * UD_WC;
+  const int Ci = a.C0 + a.C1;
+  // the conv arguments of ud_act
+  UdConvArgs ca;
+  ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
+  ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
+  ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize;
+
+  float acc[UD_WC][UD_WC][9];
+#pragma unroll
+  for (int co = 0; co < UD_WC; ++co)
+#pragma unroll
+    for (int c = 0; c < UD_WC; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[co][c][t] = 0.f;
+
+  const int y = y0 + ty, x = x0 + tx4;
+  const bool inside = (y < a.H) && (x < a.Wd);
+  for (long img = img0; img < img1; ++img) {
+    __syncthreads();
+    for (int idx = tid; idx < UD_WC * (TH + 2) * (TW + 2); idx += 256) {
+      const int c = idx / ((TH + 2) * (TW + 2)), r = idx - c * ((TH + 2) * (TW + 2));
+      const int yy = r / (TW + 2), xx = r - yy * (TW + 2);
+      tile[c][yy][xx] = (ci0 + c < Ci) ? ud_act(ca, img, ci0 + c, y0 + yy - 1, x0 + xx - 1) : 0.f;
+    }
+    float4 d[UD_WC];
+#pragma unroll
+    for (int co = 0; co < UD_WC; ++co)
+      d[co] = (inside && co0 + co < a.Co)
+                  ? *reinterpret_cast<const float4*>(&a.dy[img * a.dys + ((long)(co0 + co) * a.H + y) * a.Wd + x])
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < UD_WC; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float seg[6];
+        const float* row = &tile[c][ty + ky][tx4];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) seg[q] = row[q];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int co = 0; co < UD_WC; ++co)
+            acc[co][c][ky * 3 + kx] += d[co].x * seg[kx] + d[co].y * seg[kx + 1] + d[co].z * seg[kx + 2] + d[co].w * seg[kx + 3];
+      }
+  }
+  // fold the 256 threads: wave shuffles, then the four waves through LDS
+#pragma unroll
+  for (int co = 0; co < UD_WC; ++co)
+#pragma unroll
+    for (int c = 0; c < UD_WC; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float v = acc[co][c][t];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][(co * UD_WC + c) * 9 + t] = v;
+      }
+  __syncthreads();
+  if (tid < UD_WC * UD_WC * 9) {
+    const int co = tid / (UD_WC * 9), r = tid - co * (UD_WC * 9), c = r / 9, t = r - c * 9;
+    if (co0 + co < a.Co && ci0 + c < Ci) {
+      const long z = (long)blockIdx.y * gridDim.x + blockIdx.x;
+      a.slab[z * ((long)a.Co * Ci * 9) + ((long)(co0 + co) * Ci + ci0 + c) * 9 + t] =
+          red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+  }
+}

@@ -6,6 +6,7 @@
 // NCHW / transposed-conv gather loader; "activated views" (raw conv output + folded group-BN affine +
 // ReLU) are applied on load and never materialised.
 #include "mo_gemm.hpp"
+#include "unet_direct.hpp"
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
@@ -60,8 +61,10 @@ static void uplan(int M, int N, long P, int& nsplit, int& kchunk) {
   kchunk = (int)(per * BK);
   nsplit = (int)((P + kchunk - 1) / kchunk); if (nsplit < 1) nsplit = 1;
 }
+#define UD_MAX_SLABS 512     // direct 3x3 weight gradient: slab rows (tile positions x image ranges)
 extern "C" long mo_unet_wgrad_ws_floats(int M, int N, long P) {
   int ns, kc; uplan(M, N, P, ns, kc);
+  if (ns < UD_MAX_SLABS) ns = UD_MAX_SLABS;
   return (long)ns * M * N + 64;
 }
 
@@ -123,6 +126,21 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31) && istride0 < (1L << 31) && ostride < (1L << 31));
   const int Ci = C0 + C1;
+  // thin layers at >= 32x32 pixels: direct convolution on LDS spatial tiles (unet_direct.hpp)
+  if (Co <= 32 && H >= 32 && Wd >= 32 && n_img < 65536 && (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0) {
+    UdConvArgs a;
+    a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
+    a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
+    a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+    hipStream_t st = ST(stream);
+    const bool wide = Wd >= 64;
+    dim3 grid(mo_cdiv(Wd, wide ? 64 : 32), mo_cdiv(H, wide ? 16 : 32), (unsigned)n_img);
+#define UD_LAUNCH(CO) do { if (wide) hipLaunchKernelGGL((ud_conv3x3_kernel<CO, 16, 64>), grid, dim3(256), 0, st, a); \
+                           else hipLaunchKernelGGL((ud_conv3x3_kernel<CO, 32, 32>), grid, dim3(256), 0, st, a); } while (0)
+    if (Co <= 4) UD_LAUNCH(4); else if (Co <= 8) UD_LAUNCH(8); else if (Co <= 16) UD_LAUNCH(16); else UD_LAUNCH(32);
+#undef UD_LAUNCH
+    return mo_launch_status();
+  }
   MoOperand A = uplain(W, Ci * 9, Co, Ci * 9);   // XROWS: rows = m = co, cols = k = (ci,tap)
   MoOperand B = im2col_operand(in0, C0, istride0, sc0, sh0, relu0, in1, C1, istride1, sc1, sh1, relu1, P);
   MoEpi E; uepi(E, out, ostride);
@@ -152,6 +170,30 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31));
   const int Ci = C0 + C1;
+  if (Co <= 32 && H >= 32 && Wd >= 32 && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0) {
+    // thin layers: direct weight gradient on LDS spatial tiles (unet_direct.hpp)
+    const bool wide = Wd >= 64;
+    const int tw = wide ? 64 : 32, th = wide ? 16 : 32;
+    const long tiles = (long)mo_cdiv(Wd, tw) * mo_cdiv(H, th);
+    long ipw = (n_img * tiles + UD_MAX_SLABS - 1) / UD_MAX_SLABS;          // images per workgroup
+    if (ipw < 1) ipw = 1;
+    const long nchunk = (n_img + ipw - 1) / ipw;
+    if (tiles * nchunk <= UD_MAX_SLABS && tiles < 65536 && nchunk < 65536) {
+      UdWgradArgs a;
+      a.dy = dy; a.dys = dystride;
+      a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
+      a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
+      a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+      a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UD_WC);
+      dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)(a.n_cichunk * mo_cdiv(Co, UD_WC)));
+      hipStream_t st = ST(stream);
+      if (wide) hipLaunchKernelGGL((ud_wgrad3x3_kernel<16, 64>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((ud_wgrad3x3_kernel<32, 32>), grid, dim3(256), 0, st, a);
+      const long n = (long)Co * Ci * 9;
+      hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(256), 0, st, ws, n, (int)(tiles * nchunk), dW, n);
+      return mo_launch_status();
+    }
+  }
   MoGeom G = geom(H, Wd, gsize, C0, C1);
   MoOperand A; uop(A, Co, P); useg(A.seg[0], dy, dystride, nullptr, nullptr, 0);     // NCHW XROWS rows = co, cols = p
   MoGeom Ga = G; Ga.C0 = Co;

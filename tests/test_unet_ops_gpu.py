@@ -19,7 +19,10 @@ def act_view(y, sc, sh, gsize):
 
 
 @pytest.mark.parametrize('n,gs,C0,C1,Co,H,W', [(6, 3, 1, 0, 4, 16, 16), (4, 2, 8, 0, 8, 8, 12), (4, 2, 16, 16, 16, 8, 8),
-                                                (2, 1, 64, 0, 64, 8, 8), (3, 3, 4, 4, 4, 32, 32), (2, 2, 32, 32, 32, 16, 16)])
+                                                (2, 1, 64, 0, 64, 8, 8), (3, 3, 4, 4, 4, 32, 32), (2, 2, 32, 32, 32, 16, 16),
+                                                # direct-convolution path (thin layers at >= 32x32): ragged tiles, odd channel counts
+                                                (2, 1, 13, 0, 4, 32, 64), (2, 2, 5, 3, 13, 48, 80), (1, 1, 20, 12, 32, 32, 36),
+                                                (2, 1, 4, 0, 8, 128, 128)])
 def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W):
     lib = L.load()
     G = n // gs
