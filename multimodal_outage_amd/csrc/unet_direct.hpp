@@ -18,7 +18,7 @@ struct UdConvArgs {
 };
 
 // activated value of channel c (of the concat) at (y, x) of image img; zero outside the image
-__device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, int c, int y, int x) {
+__device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, long grp, int c, int y, int x) {
   if ((unsigned)y >= (unsigned)a.H || (unsigned)x >= (unsigned)a.Wd) return 0.f;
   const bool first = c < a.C0;
   const int cc = first ? c : c - a.C0;
@@ -29,7 +29,7 @@ __device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, int c, in
   if (sc) {
     const float* sh = first ? a.sh0 : a.sh1;
     const int C = first ? a.C0 : a.C1;
-    const long gi = (img / a.gsize) * C + cc;
+    const long gi = grp * C + cc;
     v = v * sc[gi] + sh[gi];
   }
   if (first ? a.relu0 : a.relu1) v = fmaxf(v, 0.f);
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
   const int tx4 = (tid % GX) * 4, ty = tid / GX;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const long img = blockIdx.z;
+  const long grp = img / a.gsize;
   const int Ci = a.C0 + a.C1;
   float acc[CO][4];
 #pragma unroll
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
     for (int idx = tid; idx < nc * (TH + 2) * (TW + 2); idx += 256) {
       const int c = idx / ((TH + 2) * (TW + 2)), r = idx - c * ((TH + 2) * (TW + 2));
       const int yy = r / (TW + 2), xx = r - yy * (TW + 2);
-      tile[c][yy][xx] = ud_act(a, img, c0 + c, y0 + yy - 1, x0 + xx - 1);
+      tile[c][yy][xx] = ud_act(a, img, grp, c0 + c, y0 + yy - 1, x0 + xx - 1);
     }
     for (int idx = tid; idx < nc * 9 * CO; idx += 256) {
       const int c = idx / (9 * CO), r = idx - c * (9 * CO), tap = r / CO, co = r - tap * CO;
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
 // (dy quads straight from global, the activated input halo through LDS), and the 256 threads are folded once at
 // the end (wave shuffles, then LDS).  One slab row per (tile, image range); uslab_reduce_kernel sums the rows.
 // ------------------------------------------------------------------------------------------------
-#define UD_WC 4          // channels per operand per workgroup
+#define UD_WC 4          // output channels per workgroup
+#define UD_WI 2          // input channels per workgroup (4 x 2 x 9 = 72 partial sums per thread)
 
 struct UdWgradArgs {
   const float* dy; long dys;
@@ -118,8 +120,8 @@ struct UdWgradArgs {
 template <int TH, int TW>
 __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
   constexpr int LDT = TW + 4;
-  __shared__ __attribute__((aligned(16))) float tile[UD_WC][TH + 2][LDT];
-  __shared__ float red[4][UD_WC * UD_WC * 9];
+  __shared__ __attribute__((aligned(16))) float tile[UD_WI][TH + 2][LDT];
+  __shared__ float red[4][UD_WC * UD_WI * 9];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int GX = TW / 4;
   const int tx4 = (tid % GX) * 4, ty = tid / GX;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
   const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
   const long img0 = (long)blockIdx.y * a.img_per_wg;
   const long img1 = min(img0 + a.img_per_wg, a.n_img);
-  const int ci0 = (blockIdx.z % a.n_cichunk) * UD_WC, co0 = (blockIdx.z / a.n_cichunk) * UD_WC;
+  const int ci0 = (blockIdx.z % a.n_cichunk) * UD_WI, co0 = (blockIdx.z / a.n_cichunk) * UD_WC;
   const int Ci = a.C0 + a.C1;
   // the conv arguments of ud_act
   UdConvArgs ca;
@@ -135,22 +137,23 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
   ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
   ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize;
 
-  float acc[UD_WC][UD_WC][9];
+  float acc[UD_WC][UD_WI][9];
 #pragma unroll
   for (int co = 0; co < UD_WC; ++co)
 #pragma unroll
-    for (int c = 0; c < UD_WC; ++c)
+    for (int c = 0; c < UD_WI; ++c)
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[co][c][t] = 0.f;
 
   const int y = y0 + ty, x = x0 + tx4;
   const bool inside = (y < a.H) && (x < a.Wd);
   for (long img = img0; img < img1; ++img) {
+    const long grp = img / a.gsize;
     __syncthreads();
-    for (int idx = tid; idx < UD_WC * (TH + 2) * (TW + 2); idx += 256) {
+    for (int idx = tid; idx < UD_WI * (TH + 2) * (TW + 2); idx += 256) {
       const int c = idx / ((TH + 2) * (TW + 2)), r = idx - c * ((TH + 2) * (TW + 2));
       const int yy = r / (TW + 2), xx = r - yy * (TW + 2);
-      tile[c][yy][xx] = (ci0 + c < Ci) ? ud_act(ca, img, ci0 + c, y0 + yy - 1, x0 + xx - 1) : 0.f;
+      tile[c][yy][xx] = (ci0 + c < Ci) ? ud_act(ca, img, grp, ci0 + c, y0 + yy - 1, x0 + xx - 1) : 0.f;
     }
     float4 d[UD_WC];
 #pragma unroll
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
                   : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < UD_WC; ++c)
+    for (int c = 0; c < UD_WI; ++c)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         float seg[6];
@@ -178,17 +181,17 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
 #pragma unroll
   for (int co = 0; co < UD_WC; ++co)
 #pragma unroll
-    for (int c = 0; c < UD_WC; ++c)
+    for (int c = 0; c < UD_WI; ++c)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         float v = acc[co][c][t];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wave][(co * UD_WC + c) * 9 + t] = v;
+        if (lane == 0) red[wave][(co * UD_WI + c) * 9 + t] = v;
       }
   __syncthreads();
-  if (tid < UD_WC * UD_WC * 9) {
-    const int co = tid / (UD_WC * 9), r = tid - co * (UD_WC * 9), c = r / 9, t = r - c * 9;
+  if (tid < UD_WC * UD_WI * 9) {
+    const int co = tid / (UD_WI * 9), r = tid - co * (UD_WI * 9), c = r / 9, t = r - c * 9;
     if (co0 + co < a.Co && ci0 + c < Ci) {
       const long z = (long)blockIdx.y * gridDim.x + blockIdx.x;
       a.slab[z * ((long)a.Co * Ci * 9) + ((long)(co0 + co) * Ci + ci0 + c) * 9 + t] =

@@ -184,7 +184,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
       a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
       a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
-      a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UD_WC);
+      a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UD_WI);
       dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)(a.n_cichunk * mo_cdiv(Co, UD_WC)));
       hipStream_t st = ST(stream);
       if (wide) hipLaunchKernelGGL((ud_wgrad3x3_kernel<16, 64>), grid, dim3(256), 0, st, a);
