@@ -48,7 +48,14 @@ int mo_conv1x1_fwd(const float* in, int Ci, int To, int Ti, int off, int in_relu
  * g_i[(grp, t + Tout[i] - Tf)][ci] * W_i[co][ci],  t in [0,Tf).  nl <= 8 layers per call (chain more with beta);
  * bias = the sum of the layers' biases (may be null).  g_i [G*Tout[i]][32], W_i (Cs,32,1,1), skip [G*Tf][Cs]. */
 int mo_skip_fwd(const float* const* g, const int* Tout, const float* const* W, int nl, const float* bias,
-                int Cs, long G, int Tf, float* skip, int beta, void* stream);
+                int Cs, long G, int Tf, float* skip, int beta, int relu /* 1: store relu(skip): all its consumers
+                apply ReLU (:252) */, void* skip_bf16 /* optional bf16 copy (throughput mode), may be NULL */,
+                void* stream);
+/* Data gradient of a 1x1 conv with few output channels (end_conv_2, :254): din[p][j] = (mask[p][j] > 0 ?) sum_c
+ * dout[p][c]*W[c][j]; Co <= 16, Ci % 4 == 0 and 256 % (Ci/4) == 0; mask (ReLU backward, may be NULL) and the optional
+ * bf16 copy have din's shape. */
+int mo_conv1x1_bwd_data_smallk(const float* dout, int Co, long P, const float* W, int Ci, const float* mask,
+                               float* din, void* din_bf16, void* stream);
 /* din[omap(p)][ci] (+)= sum_co dout[p][co]*W[co][ci], optionally masked by (mask[p'][ci] > 0) where p'
  * indexes the rows of din (ReLU backward); output rows mapped as above (rows without image skipped). */
 int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const float* W, int Ci, float* din,
@@ -110,6 +117,11 @@ int mo_f32_to_bf16(const float* x, void* y, long n, void* stream);
 int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
                      int ldd, int M, int N, int K, int beta, void* D_bf16, void* stream);
 int mo_f32_to_bf16_padded(const float* x, int rows, int cols, void* y, int ld_out, void* stream);
+/* mo_gemm_bf16_256 with fp32-result epilogue options (the head in the throughput mode): + bias[n], ReLU, and a
+ * ReLU-backward gate (result zeroed where mask[m][n] <= 0; mask has D's shape and leading dimension) */
+int mo_gemm_bf16_256_ex(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
+                        int ldd, int M, int N, int K, int beta, void* D_bf16, const float* bias, int relu,
+                        const float* mask, void* stream);
 
 /* ---- gcn mlp + dropout + residual + BatchNorm statistics (graph_wavenet.py:95-97,247,250) -------
  * h[p][:] = drop(W @ cat[srcs[0..ns)][p] + b) + (res[(g,t+Tin-Tout)]*rscale+rshift); per-block BN

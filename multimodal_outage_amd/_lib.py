@@ -22,7 +22,8 @@ SIGNATURES = {
     'mo_nchw_to_nbtc': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'mo_nbtc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'mo_conv1x1_fwd': (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, i32, vp]),
-    'mo_skip_fwd': (i32, [vp, vp, vp, i32, vp, i32, i64, i32, vp, i32, vp]),
+    'mo_skip_fwd': (i32, [vp, vp, vp, i32, vp, i32, i64, i32, vp, i32, i32, vp, vp]),
+    'mo_conv1x1_bwd_data_smallk': (i32, [vp, i32, i64, vp, i32, vp, vp, vp, vp]),
     'mo_conv1x1_bwd_data': (i32, [vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, vp]),
     'mo_wgrad_ws_floats': (i64, [i32, i32, i64]),
     'mo_conv1x1_bwd_weight': (i32, [vp, i32, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
@@ -38,6 +39,7 @@ SIGNATURES = {
     'mo_gemm_bf16': (i32, [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     'mo_f32_to_bf16': (i32, [vp, vp, i64, vp]),
     'mo_gemm_bf16_256': (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'mo_gemm_bf16_256_ex': (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
     'mo_f32_to_bf16_padded': (i32, [vp, i32, i32, vp, i32, vp]),
     'mo_mlp_partial_floats': (i64, [i64]),
     'mo_gcn_mlp_fwd': (i32, [vp, i32, vp, vp, i64, i32, i32, vp, vp, vp, u32, u32, f32, vp, vp, i32, vp]),

@@ -234,7 +234,8 @@ __device__ __forceinline__ void gb_dma16(const void* gsrc, uint32_t lds_byte_off
 template <bool B_KROWS>
 __global__ void __launch_bounds__(512)
 gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ D,
-                     int ldd, int M, int N, int K, int beta, unsigned short* __restrict__ Dbf) {
+                     int ldd, int M, int N, int K, int beta, unsigned short* __restrict__ Dbf,
+                     const float* __restrict__ bias, int relu, const float* __restrict__ mask) {
   __shared__ __attribute__((aligned(16))) short lds[G2_ST * G2_STAGE_SHORTS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -422,6 +423,9 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (m >= M) continue;
         float v = acc[i][j][r];
+        if (bias) v += bias[n];
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask && !(mask[(long)m * ldd + n] > 0.f)) v = 0.f;       // ReLU backward: gradient gated by the forward value
         if (D) {
           float* o = D + (long)m * ldd + n;
           if (beta) v += *o;
@@ -435,11 +439,15 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
 }
 
 // a_kpad: number of readable columns of A (>= K rounded up to 32, zero beyond K)
-extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
-                                int ldd, int M, int N, int K, int beta, void* D_bf16, void* stream) {
+// fp32-result epilogue options (the head of the throughput mode): + bias[n], ReLU, and a ReLU-backward gate
+// (result zeroed where mask[m][n] <= 0; mask has D's shape and leading dimension)
+extern "C" int mo_gemm_bf16_256_ex(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
+                                   int ldd, int M, int N, int K, int beta, void* D_bf16, const float* bias, int relu,
+                                   const float* mask, void* stream) {
   MO_CHECK_ARG(A && B && (D || D_bf16) && M > 0 && N >= 8 && K > 0);
   MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (!b_krows || (N % 8) == 0));
   MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
+  MO_CHECK_ARG(D || (!bias && !relu && !mask));      // the options live on the fp32-result path
   const int kpad = (K + 31) / 32 * 32;
   MO_CHECK_ARG(a_kpad >= kpad && lda >= kpad);
   MO_CHECK_ARG(b_krows || (K % 32) == 0);          // XROWS B has no zero-padded operand to mask a K tail
@@ -447,11 +455,15 @@ extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* 
   dim3 grid(8 * ((gm + 1) / 2) * ((gn + 3) / 4));
   if (b_krows)
     hipLaunchKernelGGL(gemm_bf16_256_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16, bias, relu, mask);
   else
     hipLaunchKernelGGL(gemm_bf16_256_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16, bias, relu, mask);
   return mo_launch_status();
+}
+extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,
+                                int ldd, int M, int N, int K, int beta, void* D_bf16, void* stream) {
+  return mo_gemm_bf16_256_ex(A, lda, a_kpad, B, ldb, b_krows, D, ldd, M, N, K, beta, D_bf16, nullptr, 0, nullptr, stream);
 }
 
 // fp32 [rows][cols] -> bf16 [rows][ld_out] with zero fill of columns [cols, ld_out)

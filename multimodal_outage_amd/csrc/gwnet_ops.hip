@@ -292,7 +292,7 @@ extern "C" int mo_conv1x1_fwd(const float* in, int Ci, int To, int Ti, int off, 
 // Every layer's skip conv in one contraction over the concatenated channel axis (K = 32 * nl): the skip tensor
 // is written once instead of being read-modified-written by each layer.
 extern "C" int mo_skip_fwd(const float* const* g, const int* Tout, const float* const* W, int nl, const float* bias,
-                           int Cs, long G, int Tf, float* skip, int beta, void* stream) {
+                           int Cs, long G, int Tf, float* skip, int beta, int relu, void* skip_bf16, void* stream) {
   MO_CHECK_ARG(g && Tout && W && skip && nl >= 1 && nl <= MO_MAX_SEG && Cs > 0 && G > 0 && Tf > 0);
   const long P = G * Tf;
   MO_CHECK_ARG(P < (1L << 31));
@@ -307,10 +307,60 @@ extern "C" int mo_skip_fwd(const float* const* g, const int* Tout, const float* 
     seg_init(Bo.seg[i], W[i], 32);
   }
   MoEpi E; epi_init(E, skip, Cs);
-  E.bias = bias; E.beta = beta;
+  E.bias = bias; E.beta = beta; E.relu = relu;                       // every consumer of skip applies ReLU first
+  E.out_bf = (unsigned short*)skip_bf16; E.bf_seg = 0;
   if (Cs <= 32)
     return launch<128, 32, 32, 4, 1, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Cs, 1, ST(stream));
   return launch<128, 128, 16, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Cs, 1, ST(stream));
+}
+
+// Data gradient of a 1x1 conv with FEW output channels (end_conv_2: Co = 12): no contraction worth a tile kernel,
+// one streaming pass -- din[p][j] = (mask[p][j] > 0) ? sum_c dout[p][c] * W[c][j] : 0, optional bf16 copy.
+// A thread owns four columns j (its 4*Co weights stay in registers) and walks the rows.
+template <int CO>
+__global__ __launch_bounds__(256) void smallk_bwd_data_kernel(const float* __restrict__ dout, int Co, long P,
+                                                             const float* __restrict__ W, int Ci,
+                                                             const float* __restrict__ mask, float* __restrict__ din,
+                                                             unsigned short* __restrict__ din_bf) {
+  const int tpr = Ci / 4;                         // threads per row
+  const int rpi = 256 / tpr;                      // rows per iteration of the block
+  const int j4 = (threadIdx.x % tpr) * 4, rl = threadIdx.x / tpr;
+  if (rl >= rpi) return;
+  float4 w[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+    w[c] = (c < Co) ? *reinterpret_cast<const float4*>(&W[(long)c * Ci + j4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long p = (long)blockIdx.x * rpi + rl; p < P; p += (long)gridDim.x * rpi) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const float d = (c < Co) ? dout[p * Co + c] : 0.f;
+      v.x += d * w[c].x; v.y += d * w[c].y; v.z += d * w[c].z; v.w += d * w[c].w;
+    }
+    if (mask) {
+      const float4 m = *reinterpret_cast<const float4*>(&mask[p * Ci + j4]);
+      v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(&din[p * Ci + j4]) = v;
+    if (din_bf) {
+      __bf16 t0 = (__bf16)v.x, t1 = (__bf16)v.y, t2 = (__bf16)v.z, t3 = (__bf16)v.w;
+      const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, t0) | ((unsigned)__builtin_bit_cast(unsigned short, t1) << 16);
+      const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, t2) | ((unsigned)__builtin_bit_cast(unsigned short, t3) << 16);
+      *reinterpret_cast<uint2*>(&din_bf[p * Ci + j4]) = make_uint2(lo, hi);
+    }
+  }
+}
+extern "C" int mo_conv1x1_bwd_data_smallk(const float* dout, int Co, long P, const float* W, int Ci, const float* mask,
+                                          float* din, void* din_bf16, void* stream) {
+  MO_CHECK_ARG(dout && W && din && Co >= 1 && Co <= 16 && P > 0 && Ci >= 4 && Ci <= 1024 && (Ci % 4) == 0);
+  MO_CHECK_ARG((256 % (Ci / 4)) == 0 || Ci / 4 > 128);
+  MO_CHECK_ARG((((uintptr_t)W) & 15) == 0 && (((uintptr_t)din) & 15) == 0 && (((uintptr_t)mask) & 15) == 0);
+  const int rpi = 256 / (Ci / 4);
+  long nb = (P + rpi - 1) / rpi;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL((smallk_bwd_data_kernel<16>), dim3((unsigned)nb), dim3(256), 0, ST(stream), dout, Co, P, W, Ci, mask,
+                     din, (unsigned short*)din_bf16);
+  return mo_launch_status();
 }
 
 extern "C" int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const float* W, int Ci, float* din,

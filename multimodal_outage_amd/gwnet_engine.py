@@ -310,17 +310,30 @@ class GwnetFunction(torch.autograd.Function):
         # skip path (graph_wavenet.py:230-236): only the last Tf steps of every layer's skip conv reach the head,
         # so all of them are ONE contraction over the concatenated channels; skip is written once
         import ctypes as _C
+        P_f = G * Tf
+        # throughput mode: the head's two real contractions (end_conv_1 forward / data gradient) run as bf16 ring-GEMM
+        # launches with bias+ReLU / ReLU-gate epilogues; skip is then stored post-ReLU (all its consumers apply ReLU)
+        head_bf = bool(use_bf and cfg.L <= 8 and cfg.Cs % 32 == 0 and cfg.Ce % 32 == 0 and cfg.Cout <= 16
+                       and 256 % (cfg.Ce // 4) == 0 and P_f < (1 << 31))
+        skip_bf = torch.empty((P_f, cfg.Cs), device=dev, dtype=torch.bfloat16) if head_bf else None
         for c0 in range(0, cfg.L, 8):
             ids = list(range(c0, min(cfg.L, c0 + 8)))
             bsum = torch.stack([p[f'skip_convs.{i}.bias'] for i in ids]).sum(0)
             touts = (_C.c_int * len(ids))(*[layers[i]['Tout'] for i in ids])
             L.call('mo_skip_fwd', L.ptr_array([layers[i]['g'] for i in ids]), touts,
                    L.ptr_array([p[f'skip_convs.{i}.weight'] for i in ids]), len(ids), L.ptr(bsum), cfg.Cs, G, Tf,
-                   L.ptr(skip), 1 if c0 > 0 else 0, st)
-        P_f = G * Tf
+                   L.ptr(skip), 1 if c0 > 0 else 0, int(head_bf), L.ptr(skip_bf), st)
         r1 = _e(P_f, cfg.Ce, dev)
-        L.call('mo_conv1x1_fwd', L.ptr(skip), cfg.Cs, 0, 0, 0, 1, L.ptr(p['end_conv_1.weight']),
-               L.ptr(p['end_conv_1.bias']), cfg.Ce, L.ptr(r1), P_f, 1, 0, st)
+        W1_bf = None
+        if head_bf:
+            W1 = p['end_conv_1.weight']
+            W1_bf = torch.empty((cfg.Ce, cfg.Cs), device=dev, dtype=torch.bfloat16)
+            L.call('mo_f32_to_bf16', L.ptr(W1), L.ptr(W1_bf), W1.numel(), st)
+            L.call('mo_gemm_bf16_256_ex', L.ptr(skip_bf), cfg.Cs, cfg.Cs, L.ptr(W1_bf), cfg.Cs, 0, L.ptr(r1), cfg.Ce,
+                   P_f, cfg.Ce, cfg.Cs, 0, None, L.ptr(p['end_conv_1.bias']), 1, None, st)
+        else:
+            L.call('mo_conv1x1_fwd', L.ptr(skip), cfg.Cs, 0, 0, 0, 1, L.ptr(p['end_conv_1.weight']),
+                   L.ptr(p['end_conv_1.bias']), cfg.Ce, L.ptr(r1), P_f, 1, 0, st)
         y_int = _e(P_f, cfg.Cout, dev)
         L.call('mo_conv1x1_fwd', L.ptr(r1), cfg.Ce, 0, 0, 0, 0, L.ptr(p['end_conv_2.weight']),
                L.ptr(p['end_conv_2.bias']), cfg.Cout, L.ptr(y_int), P_f, 0, 0, st)
@@ -332,6 +345,7 @@ class GwnetFunction(torch.autograd.Function):
         ctx.layers, ctx.x_int, ctx.adp, ctx.adpT, ctx.skip, ctx.r1 = layers, x_int, adp, adpT, skip, r1
         ctx.adp_bf = adp_bf
         ctx.mfma_bf16 = int(use_bf)
+        ctx.W1_bf = W1_bf
         ctx.params = p
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -373,15 +387,26 @@ class GwnetFunction(torch.autograd.Function):
                                 L.ptr(gW2), L.ptr(gb2), L.ptr(ws_for(cfg.Cout, cfg.Ce, P_f)), L.stream()),
                  reads=(dy_int,))
         da1 = _e(P_f, cfg.Ce, dev)
-        L.call('mo_conv1x1_bwd_data', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(p['end_conv_2.weight']), cfg.Ce,
-               L.ptr(da1), 0, 0, 0, L.ptr(r1), 0, st)
+        da1_bf = None
+        if ctx.W1_bf is not None:
+            da1_bf = torch.empty((P_f, cfg.Ce), device=dev, dtype=torch.bfloat16)
+            L.call('mo_conv1x1_bwd_data_smallk', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(p['end_conv_2.weight']), cfg.Ce,
+                   L.ptr(r1), L.ptr(da1), L.ptr(da1_bf), st)
+        else:
+            L.call('mo_conv1x1_bwd_data', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(p['end_conv_2.weight']), cfg.Ce,
+                   L.ptr(da1), 0, 0, 0, L.ptr(r1), 0, st)
         gW1 = gbuf('end_conv_1.weight', p['end_conv_1.weight']); gb1 = gbuf('end_conv_1.bias', p['end_conv_1.bias'])
         lane.run(lambda: L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, P_f, L.ptr(skip), cfg.Cs, 0, 0, 0, 1,
                                 L.ptr(gW1), L.ptr(gb1), L.ptr(ws_for(cfg.Ce, cfg.Cs, P_f)), L.stream()),
                  reads=(da1,))
         dskip = _e(P_f, cfg.Cs, dev)
-        L.call('mo_conv1x1_bwd_data', L.ptr(da1), cfg.Ce, P_f, L.ptr(p['end_conv_1.weight']), cfg.Cs,
-               L.ptr(dskip), 0, 0, 0, L.ptr(skip), 0, st)
+        if ctx.W1_bf is not None:
+            # dskip = (da1 @ W1) gated by skip > 0: W1 (Ce, Cs) row-major is the [K][N] operand as it lies
+            L.call('mo_gemm_bf16_256_ex', L.ptr(da1_bf), cfg.Ce, cfg.Ce, L.ptr(ctx.W1_bf), cfg.Cs, 1, L.ptr(dskip), cfg.Cs,
+                   P_f, cfg.Cs, cfg.Ce, 0, None, None, 0, L.ptr(skip), st)
+        else:
+            L.call('mo_conv1x1_bwd_data', L.ptr(da1), cfg.Ce, P_f, L.ptr(p['end_conv_1.weight']), cfg.Cs,
+                   L.ptr(dskip), 0, 0, 0, L.ptr(skip), 0, st)
         grads['end_conv_2.weight'], grads['end_conv_2.bias'] = gW2, gb2
         grads['end_conv_1.weight'], grads['end_conv_1.bias'] = gW1, gb1
         dbs = torch.empty(cfg.Cs, device=dev, dtype=torch.float32)
