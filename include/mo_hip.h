@@ -89,7 +89,8 @@ int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, cons
                const float* dres, float* du, float* dWf, float* dWg, float* dbf, float* dbg,
                float* dpre_ws, float* ws2, int parts /* 1: dpre + data gradient, 2: weight/bias gradients
                (needs dpre of part 1), 3: both */, int mfma_bf16 /* as in mo_tcn_fwd (data path only; the
-               weight gradients stay fp32) */, void* stream);
+               weight gradients stay fp32).  With mfma_bf16 = 1 dpre_ws holds the pre-activation gradients as bf16
+               values (a G*Tout*64 bf16 buffer suffices) */, void* stream);
 
 /* ---- diffusion graph convolution, node-axis products (nconv, graph_wavenet.py:64-66) -----------
  * Y[w][:] (+)= sum_e vals[e] * X[colidx[e]][:],  e in [rowptr[w], rowptr[w+1]);  rows of J floats.

@@ -404,10 +404,12 @@ static void rsw_launch2(const MoOperand& A, const MoOperand& B, float* slab, flo
                         bool mf, hipStream_t st) {
   size_t lds = (size_t)MA * NB * 16 * 64 * 2 * sizeof(float);
   if (mf && lds < 4 * 32 * RS_LDXB * sizeof(short)) lds = 4 * 32 * RS_LDXB * sizeof(short);   // the waves' LDS tiles
+  if (mf && lds < (size_t)4 * MA * 64 * 8 * sizeof(float)) lds = (size_t)4 * MA * 64 * 8 * sizeof(float);   // bf16-a column sums
   if (mf) {      // bf16 MFMA form (throughput mode): workgroups walk 128-row runs
     const bool bbf = NB > 1 && B.seg[1].bf16;
     dim3 g(nwg), b(256);
     if (bbf) hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, false, true>), g, b, lds, st, A, B, slab, cs, P, post_b);
+    else if (A.seg[0].bf16) hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, true, false, true>), g, b, lds, st, A, B, slab, cs, P, post_b);
     else hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, true, false>), g, b, lds, st, A, B, slab, cs, P, post_b);
     return;
   }
@@ -733,6 +735,7 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
   // 3) weight gradients: slab[co'][tau*32+ci] = sum_p dpre[p][co'] * u[(g,t+tau*d)][ci]
   if (parts & 2) {
     MoOperand A3 = op_simple(dpre_ws, 64, Pout, 64);   // KROWS rows = p, cols = co'
+    A3.seg[0].bf16 = mfma_bf16 ? 1 : 0;                // throughput mode: dpre is a bf16 tensor
     MoOperand B3; op_init(B3);
     B3.nseg = K; B3.segw = 32; B3.rows = (int)Pout; B3.cols = 32 * K;
     for (int t = 0; t < K; ++t) {
@@ -746,6 +749,7 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
     int nsplit = 0;
     rc = wgrad_run(A3, B3, Pout, 64, 32 * K, ws2, nullptr, db64, st, &done, &nsplit, mfma_bf16 != 0);
     if (rc) return rc;
+    if (mfma_bf16 && !done) return MO_EUNSUPPORTED;      // bf16 dpre exists on the row-streaming path only
     hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(mo_cdiv(64 * 32 * K, 32)), dim3(256), 0, st, ws2,
                        (long)64 * 32 * K, nsplit, K, dWf, dWg);
     if (done) {

@@ -278,14 +278,15 @@ __device__ __forceinline__ void rs_put_bf(float* X, const float4 (&v)[4], int la
 // Two accumulator registers holding rows i, i+1 of a 32x32 tile (r even) as bf16: neighbouring lanes swap one
 // value (DPP quad_perm [1,0,3,2]) so that every lane stores one packed dword -- even lanes row i, odd lanes
 // row i+1 -- instead of two 2-byte stores.  elem0 = element index of (row i, column 0).
-__device__ __forceinline__ void rs_store_bf16_pair(__amdgpu_buffer_rsrc_t r, long elem0, int n, float v0, float v1) {
+__device__ __forceinline__ void rs_store_bf16_pair(__amdgpu_buffer_rsrc_t r, long elem0, int n, float v0, float v1,
+                                                   int row_stride = 32) {
   const bool odd = n & 1;
   const float send = odd ? v0 : v1;
   const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0xB1, 0xf, 0xf, true));
   const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
   __bf16 tl = (__bf16)lo, th = (__bf16)hi;
   const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, tl) | ((unsigned)__builtin_bit_cast(unsigned short, th) << 16);
-  const long e = elem0 + (odd ? 32 : 0) + (n & ~1);
+  const long e = elem0 + (odd ? row_stride : 0) + (n & ~1);
   __builtin_amdgcn_raw_buffer_store_b32(pk, r, (int)(unsigned)(e * 2), 0, 0);
 }
 __device__ __forceinline__ void rs_put(float* X, const float4 (&v)[4], int lane) {
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_ker
   if (w >= NG) return;
   const unsigned inv16 = 65536u / To + 1u;
   const __amdgpu_buffer_rsrc_t hr = rs_rsrc(a.h_prev, a.G * Ti * 128);
-  const __amdgpu_buffer_rsrc_t outr = rs_rsrc(a.out, P * (MODE == 0 ? 128 : 256));
+  const __amdgpu_buffer_rsrc_t outr = rs_rsrc(a.out, P * (MODE == 0 ? 128 : (MF ? 128 : 256)));
   const __amdgpu_buffer_rsrc_t bfr = rs_rsrc(a.out_bf, (MODE == 0 && a.out_bf) ? P * 64 : 0);
   const __amdgpu_buffer_rsrc_t dgr = rs_rsrc(a.dg, MODE == 1 ? P * 128 : 0);
   const unsigned colb = (unsigned)((lane & 7) * 16);
@@ -684,16 +685,22 @@ __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_ker
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float f = mo_tanh(accf[r] + bfv);
-        const float g = mo_sigmoid(accg[r] + bgv);
+      for (int r = 0; r < 16; r += 2) {
+        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;          // rows m (register r) and m + 1 (r + 1)
+        const float f0 = mo_tanh(accf[r] + bfv), f1 = mo_tanh(accf[r + 1] + bfv);
+        const float g0 = mo_sigmoid(accg[r] + bgv), g1 = mo_sigmoid(accg[r + 1] + bgv);
         if (MODE == 0) {
-          rs_store_f32(outr, m * 32 + n, f * g);
-          rs_store_bf16(bfr, m * 32 + n, f * g);
+          rs_store_f32(outr, m * 32 + n, f0 * g0);
+          rs_store_f32(outr, (m + 1) * 32 + n, f1 * g1);
+          rs_store_bf16_pair(bfr, m * 32, n, f0 * g0, f1 * g1);
+        } else if (MF) {        // throughput mode: the pre-activation gradients are a bf16 [P][64] tensor
+          rs_store_bf16_pair(outr, m * 64, n, dgv[r] * g0 * (1.f - f0 * f0), dgv[r + 1] * g1 * (1.f - f1 * f1), 64);
+          rs_store_bf16_pair(outr, m * 64 + 32, n, dgv[r] * f0 * g0 * (1.f - g0), dgv[r + 1] * f1 * g1 * (1.f - g1), 64);
         } else {
-          rs_store_f32(outr, m * 64 + n, dgv[r] * g * (1.f - f * f));
-          rs_store_f32(outr, m * 64 + 32 + n, dgv[r] * f * g * (1.f - g));
+          rs_store_f32(outr, m * 64 + n, dgv[r] * g0 * (1.f - f0 * f0));
+          rs_store_f32(outr, m * 64 + 32 + n, dgv[r] * f0 * g0 * (1.f - g0));
+          rs_store_f32(outr, (m + 1) * 64 + n, dgv[r + 1] * g1 * (1.f - f1 * f1));
+          rs_store_f32(outr, (m + 1) * 64 + 32 + n, dgv[r + 1] * f1 * g1 * (1.f - g1));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void rs_tcn_du_kernel(RsTcnArgs a) {
   const long w = (long)wave * gridDim.x + blockIdx.x;
   if (w >= NG) return;
   const unsigned inv16 = 65536u / Ti + 1u;
-  const __amdgpu_buffer_rsrc_t dpr = rs_rsrc(a.dpre, a.G * To * 256);
+  const __amdgpu_buffer_rsrc_t dpr = rs_rsrc(a.dpre, a.G * To * (MF ? 128 : 256));
   const __amdgpu_buffer_rsrc_t dur = rs_rsrc(a.du, P * 128);
   const __amdgpu_buffer_rsrc_t drr = rs_rsrc(a.dres, a.dres ? a.G * To * 128 : 0);
   const unsigned colb = (unsigned)((lane & 7) * 16);
@@ -733,9 +740,23 @@ __global__ __launch_bounds__(256, 2) void rs_tcn_du_kernel(RsTcnArgs a) {
   float4 ring[RS_R][4];
   auto issue_step = [&](float4 (&dst)[4], long gi, int i) {
     const int st = i % SPB, tau = st >> 1, hh = st & 1;
-    unsigned off[4];
-    rs_tile_offsets(off, gi * 128 + (i / SPB) * 32, P, Ti, To, inv16, -tau * a.dil, 256u, colb + 128u * hh, lane);
-    rs_issue_tile(dst, dpr, off);
+    if (MF) {     // bf16 [.][64] rows: two 16-byte loads per tile, rows 16j + (lane>>2), eight columns from 8*(lane&3)
+      const long m0 = gi * 128 + (i / SPB) * 32;
+      const unsigned um0 = (unsigned)(m0 < P ? m0 : 0);
+      const unsigned g0 = um0 / Ti, t0 = um0 - g0 * Ti;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned o = 16 * j + (lane >> 2);
+        const unsigned x = t0 + o, q = (x * inv16) >> 16;
+        const int tt = (int)(x - q * Ti) - tau * a.dil;
+        const bool ok = ((unsigned)tt < To) & (m0 + o < P);
+        dst[j] = rs_load4(dpr, ok ? ((g0 + q) * To + (unsigned)tt) * 128u + 64u * hh + 16u * (lane & 3) : RS_OOB);
+      }
+    } else {
+      unsigned off[4];
+      rs_tile_offsets(off, gi * 128 + (i / SPB) * 32, P, Ti, To, inv16, -tau * a.dil, 256u, colb + 128u * hh, lane);
+      rs_issue_tile(dst, dpr, off);
+    }
   };
 #pragma unroll
   for (int i = 0; i < RS_R; ++i) issue_step(ring[i], w, i);
@@ -764,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void rs_tcn_du_kernel(RsTcnArgs a) {
 #pragma unroll
       for (int st = 0; st < SPB; ++st) {
         const int i = jb * SPB + st, slot = i % RS_R;
-        if (MF) rs_put_f2b(Xb, ring[slot], lane);
+        if (MF) rs_put_b2b(Xb, ring[slot], lane);
         else rs_put(X, ring[slot], lane);
         {
           const int in = i + RS_R;
@@ -821,7 +842,7 @@ __device__ __forceinline__ void rs_get_tr(const short* Xb, rs_v8s (&f)[2], int l
   }
 }
 
-template <int MA, int NB, bool MAPPED, bool BBF>
+template <int MA, int NB, bool MAPPED, bool BBF, bool ABF = false>    // ABF: a is stored as bf16 (the TCN's dpre)
 __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOperand B, float* __restrict__ slab,
                                                             float* __restrict__ cs, long P, int post_b) {
   extern __shared__ float rs_sm[];
@@ -841,12 +862,17 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float4 csum[MA];
+  float csum8[ABF ? MA : 1][8];        // ABF: a lane holds eight columns of its rows
 #pragma unroll
   for (int i = 0; i < MA; ++i) csum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < (ABF ? MA : 1); ++i)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) csum8[i][q] = 0.f;
 
   const unsigned To = MAPPED ? (unsigned)B.seg[0].To : 1u;
   const unsigned inv16 = 65536u / To + 1u;
-  const __amdgpu_buffer_rsrc_t ar = rs_rsrc(A.seg[0].ptr, P * LDA * 4);
+  const __amdgpu_buffer_rsrc_t ar = rs_rsrc(A.seg[0].ptr, P * LDA * (ABF ? 2 : 4));
   __amdgpu_buffer_rsrc_t br[NB];
   float4 bsc[NB], bsh[NB];
 #pragma unroll
@@ -870,9 +896,15 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
     const long row0 = gi * 128 + (i / S) * 32;
     const int t = i % S;
     if (t < MA) {
-      const unsigned base = (unsigned)(row0 * (LDA * 4)) + lane_off_a + 128u * t;
+      if (ABF) {
+        const unsigned base = (unsigned)(row0 * (LDA * 2)) + (unsigned)((lane >> 2) * (LDA * 2) + (lane & 3) * 16) + 64u * t;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dst[j] = rs_load4(ar, base + (unsigned)(8 * LDA * 4) * j);
+        for (int j = 0; j < 2; ++j) dst[j] = rs_load4(ar, base + (unsigned)(16 * LDA * 2) * j);
+      } else {
+        const unsigned base = (unsigned)(row0 * (LDA * 4)) + lane_off_a + 128u * t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = rs_load4(ar, base + (unsigned)(8 * LDA * 4) * j);
+      }
     } else {
       const int j = t - MA;
       if (MAPPED) {
@@ -900,31 +932,49 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
 #pragma unroll
         for (int ma = 0; ma < MA; ++ma) {
           const int i = jb * S + ma, slot = i % RS_R;
-          // a tile: regenerated dropout mask, column sums (the bias gradient) from the fp32 values
+          if (ABF) {
+            // bf16 a tile: straight copy into the LDS tile; column sums from the widened values (inline-asm adds
+            // behind the LDS stores, see below)
+            rs_put_b2b(Xb, ring[slot], lane);
+            asm volatile("" ::: "memory");
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float* vp = &ring[slot][j].x;
-            if (dthresh) {
-              const uint32_t e = (uint32_t)((m0 + 8 * j + (lane >> 3)) * LDA + ma * 32 + 4 * (lane & 7));
+            for (int j = 0; j < 2; ++j) {
+              const unsigned u[4] = {__float_as_uint(ring[slot][j].x), __float_as_uint(ring[slot][j].y),
+                                     __float_as_uint(ring[slot][j].z), __float_as_uint(ring[slot][j].w)};
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const uint32_t h = mo_hash32(dseed, e + q);
-                vp[q] = (h >= dthresh) ? vp[q] * dscale : 0.f;
+                const float lo = __uint_as_float(u[q] << 16), hi = __uint_as_float(u[q] & 0xffff0000u);
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum8[ABF ? ma : 0][2 * q]) : "v"(lo) : "memory");
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum8[ABF ? ma : 0][2 * q + 1]) : "v"(hi) : "memory");
               }
             }
-          }
-          rs_put_f2b(Xb, ring[slot], lane);
-          // Column sums on the VALU through inline asm: written as plain `csum += v` the compiler re-associated the
-          // sums into many partials (~60 VGPRs in this kernel).  hipcc does NOT insert the vmcnt wait for a load
-          // result that only an inline-asm operand consumes, so the adds sit BEHIND the tile's LDS stores (the
-          // "memory" clobber keeps them there): the conversions feeding those stores have already waited.
-          asm volatile("" ::: "memory");
+          } else {
+          // a tile: regenerated dropout mask, column sums (the bias gradient) from the fp32 values
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].x) : "v"(ring[slot][j].x) : "memory");
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].y) : "v"(ring[slot][j].y) : "memory");
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].z) : "v"(ring[slot][j].z) : "memory");
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].w) : "v"(ring[slot][j].w) : "memory");
+            for (int j = 0; j < 4; ++j) {
+              float* vp = &ring[slot][j].x;
+              if (dthresh) {
+                const uint32_t e = (uint32_t)((m0 + 8 * j + (lane >> 3)) * LDA + ma * 32 + 4 * (lane & 7));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const uint32_t h = mo_hash32(dseed, e + q);
+                  vp[q] = (h >= dthresh) ? vp[q] * dscale : 0.f;
+                }
+              }
+            }
+            rs_put_f2b(Xb, ring[slot], lane);
+            // Column sums on the VALU through inline asm: written as plain `csum += v` the compiler re-associated the
+            // sums into many partials (~60 VGPRs in this kernel).  hipcc does NOT insert the vmcnt wait for a load
+            // result that only an inline-asm operand consumes, so the adds sit BEHIND the tile's LDS stores (the
+            // "memory" clobber keeps them there): the conversions feeding those stores have already waited.
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].x) : "v"(ring[slot][j].x) : "memory");
+              asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].y) : "v"(ring[slot][j].y) : "memory");
+              asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].z) : "v"(ring[slot][j].z) : "memory");
+              asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[ma].w) : "v"(ring[slot][j].w) : "memory");
+            }
           }
           issue_step(ring[slot], (i + RS_R) < SPR ? gi : gnext, (i + RS_R) % SPR);
           rs_get_tr(Xb, af[ma], lane);
@@ -1007,6 +1057,22 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
   if (cs) {
     // column sums: lane holds columns 4*(lane&7)..+3 summed over its rows; fold the 8 row groups and 4 waves
     __syncthreads();
+    if (ABF) {
+      float* cb = rs_sm;                                          // [wave][MA][64 lanes][8]
+#pragma unroll
+      for (int i = 0; i < MA; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cb[((wave * MA + i) * 64 + lane) * 8 + q] = csum8[ABF ? i : 0][q];
+      __syncthreads();
+      if (tid < 32 * MA) {
+        const int i = tid >> 5, col = tid & 31;
+        float s = 0.f;
+        for (int q = 0; q < 4; ++q)
+          for (int gq = 0; gq < 16; ++gq) s += cb[(((q * MA + i) * 64) + gq * 4 + (col >> 3)) * 8 + (col & 7)];
+        cs[(long)blockIdx.x * (32 * MA) + tid] = s;
+      }
+      return;
+    }
     float4* cbuf = reinterpret_cast<float4*>(rs_sm);              // [wave][MA][64]
 #pragma unroll
     for (int i = 0; i < MA; ++i) cbuf[(wave * MA + i) * 64 + lane] = csum[i];

@@ -543,7 +543,7 @@ class GwnetFunction(torch.autograd.Function):
             du = _e(G * Tin, 32, dev)
             gWf = gbuf(f'filter_convs.{i}.weight', p[f'filter_convs.{i}.weight']); gWg = gbuf(f'gate_convs.{i}.weight', p[f'gate_convs.{i}.weight'])
             gbf = gbuf(f'filter_convs.{i}.bias', shape=(32,)); gbg = gbuf(f'gate_convs.{i}.bias', shape=(32,))
-            dpre = _e(P, 64, dev)
+            dpre = (torch.empty((P, 64), device=dev, dtype=torch.bfloat16) if ctx.mfma_bf16 else _e(P, 64, dev))
             ws2_dummy = torch.empty(16, device=dev, dtype=torch.float32)
             L.call('mo_tcn_bwd', L.ptr(ly['h_in']), L.ptr(ly['scale']), L.ptr(ly['shift']), L.ptr(ly['Wp']),
                    L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, cfg.dil[i], G,
