@@ -36,10 +36,49 @@ __device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, long grp,
   return v;
 }
 
+
+// Stage the activated halo tile of channel `c` (of the concat) into LDS rows of stride LDT: the TW interior
+// columns as aligned float4 (LDS column 4 + k), the left / right halo columns as scalars (LDS columns 3 and
+// TW + 4); rows y0-1 .. y0+TH.  Wd % 4 == 0, so an interior quad is all inside or all outside the image.
+template <int TH, int TW, int LDT>
+__device__ __forceinline__ void ud_stage_halo(float* tile /* [nc][TH+2][LDT] */, const UdConvArgs& a, long img, long grp,
+                                              int c_first, int nc, int y0, int x0, int tid) {
+  constexpr int Q = TW / 4;                                     // float4 per row
+  for (int idx = tid; idx < nc * (TH + 2) * Q; idx += 256) {
+    const int c = idx / ((TH + 2) * Q), r = idx - c * ((TH + 2) * Q);
+    const int yy = r / Q, q = r - yy * Q;
+    const int y = y0 + yy - 1, x = x0 + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)y < (unsigned)a.H && x < a.Wd) {
+      const int cg = c_first + c;
+      const bool first = cg < a.C0;
+      const int cc = first ? cg : cg - a.C0;
+      const float* base = first ? a.in0 : a.in1;
+      const long is = first ? a.is0 : a.is1;
+      v = *reinterpret_cast<const float4*>(&base[img * is + ((long)cc * a.H + y) * a.Wd + x]);
+      const float* sc = first ? a.sc0 : a.sc1;
+      if (sc) {
+        const float* sh = first ? a.sh0 : a.sh1;
+        const long gi = grp * (first ? a.C0 : a.C1) + cc;
+        const float s_ = sc[gi], t_ = sh[gi];
+        v.x = v.x * s_ + t_; v.y = v.y * s_ + t_; v.z = v.z * s_ + t_; v.w = v.w * s_ + t_;
+      }
+      if (first ? a.relu0 : a.relu1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    }
+    *reinterpret_cast<float4*>(&tile[(c * (TH + 2) + yy) * LDT + 4 + 4 * q]) = v;
+  }
+  for (int idx = tid; idx < nc * (TH + 2) * 2; idx += 256) {
+    const int c = idx / ((TH + 2) * 2), r = idx - c * ((TH + 2) * 2);
+    const int yy = r >> 1, side = r & 1;
+    tile[(c * (TH + 2) + yy) * LDT + (side ? TW + 4 : 3)] =
+        ud_act(a, img, grp, c_first + c, y0 + yy - 1, side ? x0 + TW : x0 - 1);
+  }
+}
+
 // TH x TW output pixels per workgroup (256 threads, 4 pixels along x each): (16,64) or (32,32)
 template <int CO, int TH, int TW>
 __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
-  constexpr int LDT = TW + 4;                                   // halo row stride (16-byte aligned rows)
+  constexpr int LDT = TW + 8;                                   // halo row: col 3 = x0-1, cols 4.. = interior (16-B aligned)
   __shared__ __attribute__((aligned(16))) float tile[UD_CK][TH + 2][LDT];
   __shared__ __attribute__((aligned(16))) float wsm[UD_CK][9][CO];
   const int tid = threadIdx.x;
@@ -58,12 +97,7 @@ __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
   for (int c0 = 0; c0 < Ci; c0 += UD_CK) {
     const int nc = min(UD_CK, Ci - c0);
     __syncthreads();                                            // previous stage fully consumed
-    // halo tile: columns x0-1 .. x0+TW (TW+2 values), rows y0-1 .. y0+TH
-    for (int idx = tid; idx < nc * (TH + 2) * (TW + 2); idx += 256) {
-      const int c = idx / ((TH + 2) * (TW + 2)), r = idx - c * ((TH + 2) * (TW + 2));
-      const int yy = r / (TW + 2), xx = r - yy * (TW + 2);
-      tile[c][yy][xx] = ud_act(a, img, grp, c0 + c, y0 + yy - 1, x0 + xx - 1);
-    }
+    ud_stage_halo<TH, TW, LDT>(&tile[0][0][0], a, img, grp, c0, nc, y0, x0, tid);
     for (int idx = tid; idx < nc * 9 * CO; idx += 256) {
       const int c = idx / (9 * CO), r = idx - c * (9 * CO), tap = r / CO, co = r - tap * CO;
       wsm[c][tap][co] = (co < a.Co) ? a.W[((long)co * Ci + c0 + c) * 9 + tap] : 0.f;
@@ -73,7 +107,7 @@ __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         float seg[6];
-        const float* row = &tile[c][ty + ky][tx4];
+        const float* row = &tile[c][ty + ky][tx4 + 3];
 #pragma unroll
         for (int q = 0; q < 6; ++q) seg[q] = row[q];
 #pragma unroll
@@ -119,7 +153,7 @@ struct UdWgradArgs {
 
 template <int TH, int TW>
 __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
-  constexpr int LDT = TW + 4;
+  constexpr int LDT = TW + 8;
   __shared__ __attribute__((aligned(16))) float tile[UD_WI][TH + 2][LDT];
   __shared__ float red[4][UD_WC * UD_WI * 9];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -150,11 +184,7 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
   for (long img = img0; img < img1; ++img) {
     const long grp = img / a.gsize;
     __syncthreads();
-    for (int idx = tid; idx < UD_WI * (TH + 2) * (TW + 2); idx += 256) {
-      const int c = idx / ((TH + 2) * (TW + 2)), r = idx - c * ((TH + 2) * (TW + 2));
-      const int yy = r / (TW + 2), xx = r - yy * (TW + 2);
-      tile[c][yy][xx] = (ci0 + c < Ci) ? ud_act(ca, img, grp, ci0 + c, y0 + yy - 1, x0 + xx - 1) : 0.f;
-    }
+    ud_stage_halo<TH, TW, LDT>(&tile[0][0][0], ca, img, grp, ci0, min(UD_WI, Ci - ci0), y0, x0, tid);
     float4 d[UD_WC];
 #pragma unroll
     for (int co = 0; co < UD_WC; ++co)
@@ -167,7 +197,7 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         float seg[6];
-        const float* row = &tile[c][ty + ky][tx4];
+        const float* row = &tile[c][ty + ky][tx4 + 3];
 #pragma unroll
         for (int q = 0; q < 6; ++q) seg[q] = row[q];
 #pragma unroll

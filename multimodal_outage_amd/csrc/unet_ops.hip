@@ -127,7 +127,8 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
   MO_CHECK_ARG(P < (1L << 31) && istride0 < (1L << 31) && ostride < (1L << 31));
   const int Ci = C0 + C1;
   // thin layers at >= 32x32 pixels: direct convolution on LDS spatial tiles (unet_direct.hpp)
-  if (Co <= 32 && H >= 32 && Wd >= 32 && n_img < 65536 && (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0) {
+  const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
+  if (Co <= 32 && H >= 32 && Wd >= 32 && n_img < 65536 && in_al && (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0) {
     UdConvArgs a;
     a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
     a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
@@ -170,7 +171,8 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31));
   const int Ci = C0 + C1;
-  if (Co <= 32 && H >= 32 && Wd >= 32 && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0) {
+  const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
+  if (Co <= 32 && H >= 32 && Wd >= 32 && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0) {
     // thin layers: direct weight gradient on LDS spatial tiles (unet_direct.hpp)
     const bool wide = Wd >= 64;
     const int tw = wide ? 64 : 32, th = wide ? 16 : 32;
