@@ -83,7 +83,8 @@ def main():
              "algorithmic_bytes_per_launch_avg": int(alg / nl),
              "note": f"tools/pmc_summary.py over separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of "
                      f"`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (batch {a.batch}, {a.dtype}); every "
-                     f"{a.match}* launch (incl. the 2 serial roofline steps); FETCH_SIZE x2 (gfx950 correction); "
+                     f"{a.match}* launch (incl. the 2 serial roofline steps and, in the throughput mode, the head's 2 GEMM launches per step; "
+                     f"algorithmic_bytes_per_launch_avg covers the adjacency products); FETCH_SIZE x2 (gfx950 correction); "
                      f"per-kernel table {os.path.basename(out_csv)}"}
     jp = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
     d = json.load(open(jp)) if os.path.exists(jp) else {}
