@@ -185,6 +185,35 @@ def test_gwnet_bf16_dense_mode_close_to_fp32():
         assert float((g16[k] - g32[k]).abs().max()) <= 1e-1 * s + 1e-7, k
 
 
+def test_gwnet_throughput_mode_full_size_close_to_fp32():
+    """BASELINE config 2 size (N=3000, T=12, C=32), dropout on: the throughput mode (bf16 storage + bf16 MFMA paths of
+    every row-streaming kernel, the bf16 head GEMMs, ragged 128-row runs at P = 3000*3*T') against the fp32 mode with
+    the same dropout masks (the mask is a pure function of seed and element index).  Same stated tolerances as the
+    small case; gradients of a few representative tensors."""
+    cfg = dict(B=3, N=3000, T=12, in_dim=32, out_dim=12, K=2, nsup=2, seed=920, knn=(3000, 2))
+    sup = _supports(cfg)
+    outs = {}
+    for mode in ('f32', 'bf16'):
+        m = _model(cfg, sup, dropout=0.3).train()
+        m.dense_dtype = mode
+        torch.manual_seed(5)
+        x = rand(921, (3, 32, 3000, 12)).cuda()
+        y = m(x)
+        loss = F.mse_loss(y, rand(922, tuple(y.shape)).cuda())
+        loss.backward()
+        keys = ('end_conv_1.weight', 'skip_convs.0.weight', 'gconv.3.mlp.mlp.weight', 'filter_convs.5.weight',
+                'filter_convs.5.bias', 'start_conv.weight', 'bn.2.weight')
+        g = dict(m.named_parameters())
+        outs[mode] = (y.detach(), loss.item(), {k: g[k].grad.clone() for k in keys})
+    y32, l32, g32 = outs['f32']
+    y16, l16, g16 = outs['bf16']
+    assert float((y16 - y32).abs().max()) <= 2e-2 * float(y32.abs().max())
+    assert abs(l16 - l32) <= 1e-2 * l32
+    for k in g32:
+        s = float(g32[k].abs().max())
+        assert float((g16[k] - g32[k]).abs().max()) <= 1e-1 * s + 1e-7, k
+
+
 VARIANTS = {
     'gwnet_V_nogcn': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=230, gcn_bool=False, addaptadj=True),
     'gwnet_V_static': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=240, gcn_bool=True, addaptadj=False),
