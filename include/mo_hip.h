@@ -60,6 +60,14 @@ int mo_conv1x1_bwd_data_smallk(const float* dout, int Co, long P, const float* W
  * indexes the rows of din (ReLU backward); output rows mapped as above (rows without image skipped). */
 int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const float* W, int Ci, float* din,
                         int oTo, int oTi, int ooff, const float* mask, int beta, void* stream);
+/* Few-row Linear layers against a long K (the UNet Encoder/Decoder fc1/fc2, unet.py:132-136,156-160): the same
+ * contractions as mo_conv1x1_fwd / _bwd_data (identity row map, no mask) with K split into slabs + a reduce pass.
+ * ws: mo_linear_splitk_ws_floats(P, N, K) floats, N = output columns (Co forward, Ci backward), K the contraction. */
+long mo_linear_splitk_ws_floats(long P, int N, int K);
+int mo_conv1x1_fwd_splitk(const float* in, int Ci, const float* W, const float* b, int Co, float* out, long P,
+                          int out_relu, float* ws, void* stream);
+int mo_conv1x1_bwd_data_splitk(const float* dout, int Co, long P, const float* W, int Ci, float* din, float* ws,
+                               void* stream);
 /* dW[co][ci] = sum_p dout[p][co]*f(in[map(p)][ci]);  db[co] = sum_p dout[p][co] (db may be null).
  * ws: workspace of mo_wgrad_ws_floats(Co, Ci, P) floats. */
 long mo_wgrad_ws_floats(int M, int N, long P);

@@ -24,6 +24,9 @@ SIGNATURES = {
     'mo_conv1x1_fwd': (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, i32, vp]),
     'mo_skip_fwd': (i32, [vp, vp, vp, i32, vp, i32, i64, i32, vp, i32, i32, vp, vp]),
     'mo_conv1x1_bwd_data_smallk': (i32, [vp, i32, i64, vp, i32, vp, vp, vp, vp]),
+    'mo_linear_splitk_ws_floats': (i64, [i64, i32, i32]),
+    'mo_conv1x1_fwd_splitk': (i32, [vp, i32, vp, vp, i32, vp, i64, i32, vp, vp]),
+    'mo_conv1x1_bwd_data_splitk': (i32, [vp, i32, i64, vp, i32, vp, vp, vp]),
     'mo_conv1x1_bwd_data': (i32, [vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, vp]),
     'mo_wgrad_ws_floats': (i64, [i32, i32, i64]),
     'mo_conv1x1_bwd_weight': (i32, [vp, i32, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),

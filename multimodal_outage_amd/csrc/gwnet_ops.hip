@@ -376,6 +376,63 @@ extern "C" int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const floa
   return launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, 1, ST(stream));
 }
 
+// Few-row Linear layers against long K (the UNet Encoder/Decoder fc layers: ~134 rows x K = 16384): the tile grid
+// alone is 10..26 workgroups, so K is split over blockIdx.z into slabs and a second pass sums them (+ bias, ReLU).
+__global__ void linear_splitk_reduce_kernel(const float* __restrict__ ws, long stride, int nz, const float* __restrict__ bias,
+                                            int ld, int relu, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = bias ? bias[i % ld] : 0.f;
+  for (int z = 0; z < nz; ++z) s += ws[(long)z * stride + i];
+  out[i] = relu ? fmaxf(s, 0.f) : s;
+}
+static int linear_splitk_plan(long P, int N, int K, int& nz, int& kchunk) {
+  const long tiles = (long)mo_cdiv(P, 128) * mo_cdiv(N, 128);
+  long want = 512 / tiles; if (want < 1) want = 1;
+  long maxz = K / 512; if (maxz < 1) maxz = 1;                 // at least 512 of K per slab
+  if (want > maxz) want = maxz;
+  if (want > 64) want = 64;
+  kchunk = (int)(((K + want - 1) / want + 15) / 16 * 16);
+  nz = (K + kchunk - 1) / kchunk;
+  return nz;
+}
+extern "C" long mo_linear_splitk_ws_floats(long P, int N, int K) {
+  int nz, kc; linear_splitk_plan(P, N, K, nz, kc);
+  return (long)nz * P * N + 64;
+}
+extern "C" int mo_conv1x1_fwd_splitk(const float* in, int Ci, const float* W, const float* b, int Co, float* out,
+                                     long P, int out_relu, float* ws, void* stream) {
+  MO_CHECK_ARG(in && W && out && ws && Ci > 0 && Co > 0 && P > 0 && P < (1L << 31));
+  int nz, kchunk; linear_splitk_plan(P, Co, Ci, nz, kchunk);
+  if (nz <= 1) return mo_conv1x1_fwd(in, Ci, 0, 0, 0, 0, W, b, Co, out, P, out_relu, 0, stream);
+  MoOperand A = op_simple(in, Ci, P, Ci);
+  MoOperand Bo = op_simple(W, Ci, Co, Ci);     // XROWS: rows = n = co, cols = k = ci
+  MoEpi E; epi_init(E, ws, Co);
+  E.slab_stride = P * (long)Co; E.kchunk = kchunk;
+  int rc = launch<128, 128, 16, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Co, nz, ST(stream));
+  if (rc) return rc;
+  const long n = P * (long)Co;
+  hipLaunchKernelGGL(linear_splitk_reduce_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), ws, n, nz, b, Co,
+                     out_relu, out, n);
+  return mo_launch_status();
+}
+extern "C" int mo_conv1x1_bwd_data_splitk(const float* dout, int Co, long P, const float* W, int Ci, float* din,
+                                          float* ws, void* stream) {
+  MO_CHECK_ARG(dout && W && din && ws && Ci > 0 && Co > 0 && P > 0 && P < (1L << 31));
+  int nz, kchunk; linear_splitk_plan(P, Ci, Co, nz, kchunk);
+  if (nz <= 1) return mo_conv1x1_bwd_data(dout, Co, P, W, Ci, din, 0, 0, 0, nullptr, 0, stream);
+  MoOperand A = op_simple(dout, Co, P, Co);     // XROWS: rows = m = p, cols = k = co
+  MoOperand Bo = op_simple(W, Ci, Co, Ci);      // KROWS: rows = k = co, cols = n = ci
+  MoEpi E; epi_init(E, ws, Ci);
+  E.slab_stride = P * (long)Ci; E.kchunk = kchunk;
+  int rc = launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, nz, ST(stream));
+  if (rc) return rc;
+  const long n = P * (long)Ci;
+  hipLaunchKernelGGL(linear_splitk_reduce_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), ws, n, nz,
+                     (const float*)nullptr, Ci, 0, din, n);
+  return mo_launch_status();
+}
+
 // generic weight-gradient: slab[z][M][N] = sum_{k in chunk z} A(k,m) B(k,n), then reduce.  When `db` is
 // given, the column sums of A (the bias gradient) are produced by the same pass (fast loader) or by a
 // separate column-sum kernel over `a_plain` [P][M] (generic loader; a_plain may be null if impossible).

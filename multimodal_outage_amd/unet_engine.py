@@ -136,6 +136,11 @@ def _fc_fwd(x, W, b, relu):
     P, Ci = x.shape
     Co = W.shape[0]
     out = _empty(P, Co, dev=x.device)
+    if Ci >= 2048 and P <= 1024:        # few rows x long K: split-K (the tile grid alone would be ~20 workgroups)
+        ws = torch.empty(L.load().mo_linear_splitk_ws_floats(P, Co, Ci), device=x.device, dtype=torch.float32)
+        L.call('mo_conv1x1_fwd_splitk', L.ptr(x), Ci, L.ptr(W), L.ptr(b), Co, L.ptr(out), P, 1 if relu else 0,
+               L.ptr(ws), L.stream())
+        return out
     L.call('mo_conv1x1_fwd', L.ptr(x), Ci, 0, 0, 0, 0, L.ptr(W), L.ptr(b), Co, L.ptr(out), P, 1 if relu else 0, 0,
            L.stream())
     return out
@@ -175,6 +180,10 @@ def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True):
         if not need_in:
             return None
         din = _empty(P, Ci, dev=dev)
+        if Co >= 2048 and P <= 1024:
+            wsd = torch.empty(lib.mo_linear_splitk_ws_floats(P, Ci, Co), device=dev, dtype=torch.float32)
+            L.call('mo_conv1x1_bwd_data_splitk', L.ptr(dout), Co, P, L.ptr(W), Ci, L.ptr(din), L.ptr(wsd), st)
+            return din
         L.call('mo_conv1x1_bwd_data', L.ptr(dout), Co, P, L.ptr(W), Ci, L.ptr(din), 0, 0, 0, None, 0, st)
         return din
 

@@ -281,6 +281,26 @@ def test_spmm_and_dense_products(L, N, J):
             close(dA, X @ dY.t() + (dA0 if beta else 0), what=f'adj_grad beta={beta}')
 
 
+@pytest.mark.parametrize('P,Ci,Co', [(134, 16384, 1638), (67, 4096, 200), (20, 600, 40)])
+def test_linear_splitk(L, P, Ci, Co):
+    """Few-row Linear layers against a long K (UNet Encoder/Decoder fc, unet.py:132-136,156-160): split-K forward
+    (+bias, ReLU) and data gradient vs torch."""
+    lib = L.load()
+    x = rand(70, (P, Ci)); W = rand(71, (Co, Ci)) / np.sqrt(Ci); b = rand(72, (Co,))
+    out = torch.empty(P, Co, device='cuda')
+    ws = torch.empty(lib.mo_linear_splitk_ws_floats(P, Co, Ci), device='cuda')
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    for relu in (0, 1):
+        L.call('mo_conv1x1_fwd_splitk', L.ptr(xd), Ci, L.ptr(Wd), L.ptr(bd), Co, L.ptr(out), P, relu, L.ptr(ws), L.stream())
+        ref = x @ W.t() + b
+        close(out, F.relu(ref) if relu else ref, what=f'linear split-K fwd relu={relu}')
+    dout = rand(73, (P, Co))
+    din = torch.empty(P, Ci, device='cuda')
+    ws2 = torch.empty(lib.mo_linear_splitk_ws_floats(P, Ci, Co), device='cuda')
+    L.call('mo_conv1x1_bwd_data_splitk', L.ptr(dev(dout)), Co, P, L.ptr(Wd), Ci, L.ptr(din), L.ptr(ws2), L.stream())
+    close(din, dout @ W, what='linear split-K bwd data')
+
+
 def test_gemm_fragment_layout_asymmetric(L):
     """A = I with an ASYMMETRIC B: catches a transposed MFMA C-write (guide section 3)."""
     N, J = 128, 256
