@@ -172,8 +172,9 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
   MO_CHECK_ARG(P < (1L << 31));
   const int Ci = C0 + C1;
   const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
-  if (Co <= 32 && H >= 32 && Wd >= 32 && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0) {
-    // thin layers: direct weight gradient on LDS spatial tiles (unet_direct.hpp)
+  if (Co <= 32 && (long)Co * Ci <= 128 && H >= 32 && Wd >= 32 && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0) {
+    // thin layers (Co*Ci <= 128, measured crossover: beyond it the 4x2-channel blocking re-reads dy / the halo too
+    // often and the split-K implicit GEMM wins): direct weight gradient on LDS spatial tiles (unet_direct.hpp)
     const bool wide = Wd >= 64;
     const int tw = wide ? 64 : 32, th = wide ? 16 : 32;
     const long tiles = (long)mo_cdiv(Wd, tw) * mo_cdiv(H, th);
