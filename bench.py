@@ -196,6 +196,7 @@ def main():
     model.dense_dtype = args.dtype
     trainer = FlatTrainer(model, lr=1e-3)
     model._mo_grad_out = trainer.grad_out()
+    model._mo_grad_ready = trainer.ready_callback()     # gradient all-reduce starts inside backward (N > 1)
     B = args.batch
     g = torch.Generator().manual_seed(1000 + rank)
     x = torch.randn(B, C_IN, N_NODES, T_IN, generator=g).to(dev)

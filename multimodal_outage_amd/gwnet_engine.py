@@ -55,6 +55,7 @@ class GwnetConfig:
         self.gcn, self.adaptive, self.dropout = gcn, adaptive, dropout
         self.names = names            # parameter order of the autograd Function
         self.grad_out = None          # optional {name: preallocated grad tensor} (flat-buffer trainer)
+        self.grad_ready = None        # optional callback(names): these gradients are final (overlapped all-reduce)
         self.dense_bf16 = False       # bf16 operands (fp32 accumulate) for the dense adaptive products
         self.overlap = True           # dense branch on a side stream beside the sparse branch
 
@@ -558,6 +559,18 @@ class GwnetFunction(torch.autograd.Function):
             lane.run(_tcn_w, reads=(dpre, dg))
             grads[f'filter_convs.{i}.weight'], grads[f'filter_convs.{i}.bias'] = gWf, gbf
             grads[f'gate_convs.{i}.weight'], grads[f'gate_convs.{i}.bias'] = gWg, gbg
+            if cfg.grad_ready is not None and i == cfg.L // 2 and cfg.L > 1:
+                # data-parallel overlap: the head's and the late layers' gradients are final -- hand them to the
+                # trainer's asynchronous all-reduce now, behind everything queued on the main and lane streams
+                late = [n for n in cfg.names if n.startswith('end_conv_') or
+                        (len(n.split('.')) > 2 and n.split('.')[1].isdigit() and int(n.split('.')[1]) >= i)]
+                late = [n for n in late if n in gout and gout[n] is not None]
+                if lane.side is not None:
+                    lane.side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(lane.side):
+                        cfg.grad_ready(late)
+                else:
+                    cfg.grad_ready(late)
             dxo = du
 
         # ---- start conv (graph_wavenet.py:191-196)
@@ -593,6 +606,8 @@ class GwnetFunction(torch.autograd.Function):
             grads['nodevec1'], grads['nodevec2'] = gE1, gE2
 
         lane.join()
+        if cfg.grad_ready is not None:
+            cfg.grad_ready([n for n in cfg.names if n in gout and gout[n] is not None])
         # gradients written straight into registered flat-buffer views are not handed to autograd
         return (None, None, None, None, dx) + tuple(
             None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)

@@ -226,6 +226,7 @@ class gwnet(nn.Module):
                           gcn=self._use_gcn(), adaptive=self._use_gcn() and self.addaptadj,
                           dropout=self.dropout, names=names)
         cfg.grad_out = getattr(self, '_mo_grad_out', None)
+        cfg.grad_ready = getattr(self, '_mo_grad_ready', None)
         cfg.dense_bf16 = (getattr(self, 'dense_dtype', 'f32') == 'bf16')
         bn_bufs = [(m.running_mean, m.running_var) for m in self.bn]
         if self.training:

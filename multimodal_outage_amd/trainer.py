@@ -1,11 +1,18 @@
 """Data-parallel training plumbing for the HIP path: flat fp32 parameter / gradient / Adam-state
-buffers, one-bucket RCCL all-reduce, fused Adam (torch.optim.Adam semantics, lit.py:59-61).
+buffers, bucketed RCCL all-reduce overlapped with backward, fused Adam (torch.optim.Adam semantics, lit.py:59-61).
 
 One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI inside a node).
 The reference has no explicit distributed code (Lightning's default DDP, lit.py:204): this is the
 MI355X-native equivalent -- replicas with per-rank BatchNorm statistics (no SyncBN, as in the
 reference), gradients averaged across ranks each step.  Parameters that never receive a gradient
 (residual_convs.*, gconv.7, bn.7 -- SURVEY.md 3.4) keep zero gradients, identically on all ranks.
+
+Overlap: the engines call ``mark_ready(names)`` from inside backward as soon as a group of gradients is final
+(end of each autograd Function; Graph-WaveNet additionally after the late half of its layers).  The covering
+ranges of the flat gradient buffer are all-reduced asynchronously right there -- RCCL orders the collective behind
+the work already queued on the calling stream and runs it beside the rest of backward -- and ``allreduce()`` at
+the end of the step reduces whatever was not announced and waits for the handles.  One backward pass per
+allreduce(): a range whose all-reduce has started must not be accumulated into again before the wait.
 """
 import math
 
@@ -18,8 +25,9 @@ _ALIGN = 64   # floats (256 B): every parameter starts on a 16-byte boundary for
 
 
 class FlatTrainer:
-    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap=True):
         self.module = module
+        self.overlap = overlap   # False: nothing starts inside backward, allreduce() reduces the whole buffer
         self.lr, self.betas, self.eps = lr, betas, eps
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -43,6 +51,24 @@ class FlatTrainer:
             self.grad_views[k] = gv
         self.step_count = 0
         self.total = total
+        self._span = {k: (o, o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN) for (k, p), o in zip(params, offs)}
+        self._done = []          # [lo, hi) ranges already handed to an asynchronous all-reduce this step
+        self._work = []
+        # buckets = top-level child modules; a bucket whose parameters have all received their gradient through
+        # autograd is announced from the post-accumulate hook of the last one (parameters an engine writes directly
+        # are announced by the engine itself through ready_callback, earlier than their hooks -- which this torch
+        # fires for every AccumulateGrad node of a finished Function, None gradients included -- would)
+        self._bucket = {k: k.split('.')[0] for k, _ in params}
+        self._bucket_names, self._bucket_total = {}, {}
+        for k, p in params:
+            self._bucket_names.setdefault(self._bucket[k], []).append(k)
+            if p.requires_grad:
+                self._bucket_total[self._bucket[k]] = self._bucket_total.get(self._bucket[k], 0) + 1
+        self._bucket_left = dict(self._bucket_total)
+        if self.world > 1 and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
+            for k, p in params:
+                if p.requires_grad:
+                    p.register_post_accumulate_grad_hook(lambda _p, k=k: self._on_grad(k))
         if self.world > 1:
             # replicas start identical: rank-0 broadcast of parameters and buffers (DDP default)
             dist.broadcast(self.flat_p, 0, group=self.pg)
@@ -56,9 +82,49 @@ class FlatTrainer:
     def zero_grad(self):
         self.flat_g.zero_()
 
+    def ready_callback(self, prefix=''):
+        """Callback for an engine: cb(names) announces that the gradients of `names` (without `prefix`) are final."""
+        return lambda names: self.mark_ready([prefix + n for n in names])
+
+    def _on_grad(self, k):
+        b = self._bucket[k]
+        self._bucket_left[b] -= 1
+        if self._bucket_left[b] == 0:
+            self._bucket_left[b] = self._bucket_total[b]     # re-armed for the next backward pass
+            self.mark_ready(self._bucket_names[b])
+
+    def mark_ready(self, names):
+        """Start the all-reduce of the flat-gradient ranges covering `names` (maximal runs of adjacent parameters);
+        call on the stream the gradients were produced on.  No-op for a single process."""
+        if self.world <= 1 or not self.overlap:
+            return
+        spans = sorted(self._span[k] for k in names if k in self._span)
+        runs = []
+        for lo, hi in spans:
+            if runs and lo <= runs[-1][1]:
+                runs[-1][1] = max(runs[-1][1], hi)
+            else:
+                runs.append([lo, hi])
+        for lo, hi in runs:
+            if any(lo < dhi and dlo < hi for dlo, dhi in self._done):
+                continue                     # (part of) the run was announced before: leave it to the final pass
+            self._work.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._done.append((lo, hi))
+
     def allreduce(self, async_op=False):
-        if self.world > 1:
-            return dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        """Reduce every range not announced through mark_ready, then wait for the asynchronous buckets."""
+        if self.world <= 1:
+            return None
+        done = sorted(self._done)
+        pos = 0
+        for lo, hi in done + [(self.total, self.total)]:
+            if lo > pos:
+                self._work.append(dist.all_reduce(self.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.pg,
+                                                  async_op=True))
+            pos = max(pos, hi)
+        for w in self._work:
+            w.wait()
+        self._work, self._done = [], []
         return None
 
     def step(self):

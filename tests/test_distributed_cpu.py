@@ -1,6 +1,6 @@
 """world_size-2 gloo test of the data-parallel plumbing (runs on CPU): rank-0 broadcast of the flat
-parameter buffer and buffers, one-bucket gradient all-reduce with 1/world averaging, identical
-handling of never-touched (zero) gradients on all ranks."""
+parameter buffer and buffers, gradient all-reduce (explicit and bucketed from inside backward) with 1/world
+averaging, identical handling of never-touched (zero) gradients on all ranks."""
 import os
 import socket
 
@@ -42,7 +42,25 @@ def _worker(rank, world, port, q):
                 g.fill_(float(rank + 1))
         tr.allreduce()
         summed = {k: float(g.flatten()[0]) for k, g in tr.grad_views.items()}
-        q.put((rank, same, buf_ok, views_ok, summed, tr.world))
+        # overlapped path: a real backward fires the post-accumulate hooks, every top-level child is announced as a
+        # bucket from inside backward, allreduce() only waits; the result must be the sum of both ranks' gradients
+        import copy
+        refm = copy.deepcopy(m)
+        for p_ in refm.parameters():
+            p_.grad = None
+        tr.zero_grad()
+        xs = [torch.full((2, 3, 4, 7), float(r + 1)) + torch.arange(7.0) for r in range(world)]
+        m(xs[rank]).square().sum().backward()
+        announced = len(tr._done)
+        tr.allreduce()
+        want = {k: torch.zeros_like(v) for k, v in refm.named_parameters()}
+        for r in range(world):
+            refm2 = copy.deepcopy(refm)
+            refm2(xs[r]).square().sum().backward()
+            for k, v in refm2.named_parameters():
+                want[k] += v.grad
+        bucket_ok = announced == 3 and all(torch.allclose(tr.grad_views[k], want[k], rtol=1e-5, atol=1e-5) for k in want)
+        q.put((rank, same, buf_ok, views_ok, summed, tr.world, bucket_ok))
     finally:
         dist.destroy_process_group()
 
@@ -59,7 +77,7 @@ def test_flat_trainer_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, same, buf_ok, views_ok, summed, w in res:
-        assert same and buf_ok and views_ok and w == 2
+    for rank, same, buf_ok, views_ok, summed, w, bucket_ok in res:
+        assert same and buf_ok and views_ok and w == 2 and bucket_ok
         for k, v in summed.items():
             assert v == (0.0 if k == '2.bias' else 3.0), (k, v)     # 1 + 2 summed; Adam divides by world
