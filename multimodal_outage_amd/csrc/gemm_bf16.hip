@@ -201,7 +201,12 @@ extern "C" int mo_f32_to_bf16(const float* x, void* y, long n, void* stream) {
 
 // ================================================================================================
 // 256x256x32 tile, 8 waves (2x4 of 128x64), 4-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4)
-// with three k-tiles in flight behind counted vmcnt waits and one raw s_barrier per k-tile.
+// behind counted vmcnt waits and one raw s_barrier per k-tile; the k loop is software-pipelined by half k-tiles
+// (LDS reads of the next 16 k in flight under the 8 MFMAs of the current 16 k, hand-counted lgkmcnt).
+// What bounds it (probes of round 1, J = 24576, bf16 result: DMA only 284 us, MFMA + LDS reads only 295 us, both
+// 419 us): the L2 -> LDS fill of 32 KB per k-tile and CU (about 53 GB/s per CU alone, less at the clock the MFMAs
+// leave) runs at the same pace as the 1024 MFMA cycles per k-tile -- a 256x256 tile is the largest accumulator two
+// waves per SIMD can hold, so this fill rate, not the matrix pipe, is the kernel's ceiling.
 //   throughput model of the 128^2 kernel above: (bytes in flight per CU) x (flop per byte of the tile)
 //   / (L2/MALL latency) -- 64 KB x 64 flop/B / ~2.4 us x 256 CUs ~ 0.45 PF, which is what it measures.
 //   This kernel has 96 KB in flight at 128 flop/B.
@@ -223,6 +228,23 @@ __device__ __forceinline__ void gb_dma16(const void* gsrc, uint32_t lds_byte_off
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_byte_off)
                : "memory");
+}
+
+// LDS fragment reads from inline asm (immediate offsets), for the software-pipelined k loop: hipcc's own lgkmcnt
+// bookkeeping drains every outstanding LDS read at the loop head (s_waitcnt lgkmcnt(0)), which would serialise the
+// reads of the next half k-tile with the MFMAs of the current one; these are invisible to it and are awaited by
+// hand-counted s_waitcnt lgkmcnt(N) (LDS returns in order; the loop holds no scalar loads).
+template <int OFF>
+__device__ __forceinline__ v8s g2_lds128(uint32_t addr) {
+  v8s r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ v4s g2_ldstr(uint32_t addr) {
+  v4s r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
 }
 
 #define G2_BM 256
@@ -307,49 +329,110 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
 
   const int fr = lane & 31, fh = lane >> 5;
   const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  for (int kt = 0; kt < nk; ++kt) {
-    // the 4 oldest DMAs of this wave (stage kt) must have landed; younger stages stay in flight
-    // (one barrier per TWO k-tiles with a two-pair ring measured 6-14 % slower: less prefetch depth)
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  auto mma = [&](const v8s (&a)[4], const v8s (&b)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[i]),
+                                                             __builtin_bit_cast(v8bf, b[j]), acc[i][j], 0, 0, 0);
+  };
+  {
+    // software-pipelined: the LDS reads of the next half k-tile are in flight under the MFMAs of the current one.
+    // Stage kt+1 is awaited (own DMAs: vmcnt; everybody's: barrier) in the MIDDLE of k-tile kt, where the refill of
+    // the stage consumed in k-tile kt-1 is issued too: two k-tiles of DMA in flight, one landed, one being read.
+    // per-lane byte addresses inside a stage (the swizzle makes s / j an XOR, not an add, where noted)
+    uint32_t aA[2], aB[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int x = wm0 + fr;                                  // + 32 i rows = + 2048 i bytes (swizzle unchanged)
+      aA[q] = lds_base + (uint32_t)(x * 64 + (((2 * q + fh) ^ ((x >> 2) & 3)) << 4));
+      if (B_KROWS) {                                           // q = j; s adds 16 k rows = 8192 bytes
+        const int kr = 8 * (tg >> 1) + tq;
+        const int nc = wn0 + q * 32 + 16 * (tg & 1) + 4 * tp;
+        const int ph = (nc >> 3) ^ ((kr & 3) << 2);
+        aB[q] = lds_base + 16384u + (uint32_t)(2 * (kr * 256 + ph * 8 + (nc & 7)));
+      } else {                                                 // q = s; j adds 32 rows = 2048 bytes
+        const int xb = wn0 + fr;
+        aB[q] = lds_base + 16384u + (uint32_t)(xb * 64 + (((2 * q + fh) ^ ((xb >> 2) & 3)) << 4));
+      }
+    }
+    auto rd0 = [&](int kt, v8s (&a)[4], v8s (&b)[2]) {           // first half (k 0..15) of stage kt
+      const uint32_t so = (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+      const uint32_t pa = aA[0] + so;
+      a[0] = g2_lds128<0>(pa); a[1] = g2_lds128<2048>(pa); a[2] = g2_lds128<4096>(pa); a[3] = g2_lds128<6144>(pa);
+      if (B_KROWS) {
+        const uint32_t p0 = aB[0] + so, p1 = aB[1] + so;
+        v4s l0 = g2_ldstr<0>(p0), h0 = g2_ldstr<2048>(p0), l1 = g2_ldstr<0>(p1), h1 = g2_ldstr<2048>(p1);
+        b[0] = (v8s){l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
+        b[1] = (v8s){l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
+      } else {
+        const uint32_t pb = aB[0] + so;
+        b[0] = g2_lds128<0>(pb); b[1] = g2_lds128<2048>(pb);
+      }
+    };
+    auto rd1 = [&](int kt, v8s (&a)[4], v8s (&b)[2]) {           // second half (k 16..31)
+      const uint32_t so = (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+      const uint32_t pa = aA[1] + so;
+      a[0] = g2_lds128<0>(pa); a[1] = g2_lds128<2048>(pa); a[2] = g2_lds128<4096>(pa); a[3] = g2_lds128<6144>(pa);
+      if (B_KROWS) {
+        const uint32_t p0 = aB[0] + so, p1 = aB[1] + so;
+        v4s l0 = g2_ldstr<8192>(p0), h0 = g2_ldstr<10240>(p0), l1 = g2_ldstr<8192>(p1), h1 = g2_ldstr<10240>(p1);
+        b[0] = (v8s){l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
+        b[1] = (v8s){l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
+      } else {
+        const uint32_t pb = aB[1] + so;
+        b[0] = g2_lds128<0>(pb); b[1] = g2_lds128<2048>(pb);
+      }
+    };
+    // LDS reads per half k-tile and wave: 4 A + (4 transposing | 2 plain) B
+#define G2_WAIT_PREV() do { if (B_KROWS) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); \
+                            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); } while (0)
+    v8s a0[4], b0[2], a1[4], b1[2];
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + G2_ST - 1 < nk) issue(kt + G2_ST - 1);      // refills the stage consumed in iteration kt-1
-    const short* Ac = lds + (kt % G2_ST) * G2_STAGE_SHORTS;
-    const short* Bc = Ac + 8192;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      v8s a[4], b[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int x = wm0 + i * 32 + fr;
-        const int ph = (2 * s + fh) ^ ((x >> 2) & 3);
-        a[i] = *reinterpret_cast<const v8s*>(&Ac[x * 32 + ph * 8]);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (B_KROWS) {
-          const int kr = 16 * s + 8 * (tg >> 1) + tq;
-          const int nc = wn0 + j * 32 + 16 * (tg & 1) + 4 * tp;
-          const int ph = (nc >> 3) ^ ((kr & 3) << 2);
-          const int off = kr * 256 + ph * 8 + (nc & 7);
-          v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)&Bc[off]);
-          v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)&Bc[off + 4 * 256]);
-          b[j] = (v8s){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        } else {
-          const int x = wn0 + j * 32 + fr;
-          const int ph = (2 * s + fh) ^ ((x >> 2) & 3);
-          b[j] = *reinterpret_cast<const v8s*>(&Bc[x * 32 + ph * 8]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[i]),
-                                                               __builtin_bit_cast(v8bf, b[j]), acc[i][j], 0, 0, 0);
+    rd0(0, a0, b0);
+    int kt = 0;
+    for (; kt + G2_ST - 1 < nk; ++kt) {          // branch-free steady state
+      rd1(kt, a1, b1);
+      G2_WAIT_PREV();                            // a0/b0 have landed; a1/b1 stay in flight under the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(kt + G2_ST - 1);
+      rd0(kt + 1, a0, b0);
+      G2_WAIT_PREV();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    for (; kt < nk; ++kt) {                      // last three k-tiles: nothing left to issue
+      rd1(kt, a1, b1);
+      G2_WAIT_PREV();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        rd0(kt + 1, a0, b0);
+        G2_WAIT_PREV();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef G2_WAIT_PREV
   }
 
   if (!D) {
