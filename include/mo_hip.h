@@ -132,6 +132,13 @@ int mo_gemm_bf16_256_ex(const void* A, int lda, int a_kpad, const void* B, int l
                         int ldd, int M, int N, int K, int beta, void* D_bf16, const float* bias, int relu,
                         const float* mask, void* stream);
 
+/* Weight gradient of a wide 1x1 conv (end_conv_1, graph_wavenet.py:174-177 backward) in the throughput mode:
+ * dW[M][N] = A^T B over K rows with BOTH operands k-major as they lie in HBM (A: bf16 [K][M] output-gradient rows,
+ * B: bf16 [K][N] input rows), split-K ring GEMM + fixed-order slab reduction.  K % 32 == 0; M, N, lda, ldb % 8 == 0. */
+long mo_wgrad_bf16_kk_ws_floats(int M, int N, long K);
+int mo_wgrad_bf16_kk(const void* A, int lda, const void* B, int ldb, long K, int M, int N, float* dW, float* ws,
+                     void* stream);
+
 /* ---- gcn mlp + dropout + residual + BatchNorm statistics (graph_wavenet.py:95-97,247,250) -------
  * h[p][:] = drop(W @ cat[srcs[0..ns)][p] + b) + (res[(g,t+Tin-Tout)]*rscale+rshift); per-block BN
  * partial sums go to `partial` (mo_mlp_partial_floats(P) floats). ns = 2S+1 sources of [P][32].

@@ -550,6 +550,199 @@ extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* 
 }
 
 // fp32 [rows][cols] -> bf16 [rows][ld_out] with zero fill of columns [cols, ld_out)
+// ================================================================================================
+// Weight gradient of a wide 1x1 conv as a split-K ring GEMM with BOTH operands k-major as they lie in HBM:
+//   dW[m][n] = sum_k A[k][m] * B[k][n]      A: bf16 [K][M] (output gradient rows), B: bf16 [K][N] (input rows)
+// Same 256x256x32 tile / 4-stage LDS-DMA ring / half-k-tile software pipeline as gemm_bf16_256_kernel; both LDS
+// images are [k][512 B] (slot16 ^= (k&3)<<2) and both fragment kinds come from ds_read_b64_tr_b16.
+// grid = (tiles, splits): split z owns k-tiles [z*kts, min((z+1)*kts, K/32)) and stores its fp32 tile to
+// slab[z][M][N]; kk_reduce_kernel sums the slabs in a fixed order (deterministic).  K % 32 == 0, M, N % 8 == 0.
+// ================================================================================================
+__global__ void __launch_bounds__(512)
+gemm_bf16_kk_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ slab,
+                    int M, int N, int nkt, int kts) {
+  __shared__ __attribute__((aligned(16))) short lds[G2_ST * G2_STAGE_SHORTS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+  const int gn = (N + G2_BN - 1) / G2_BN;
+  const int m0 = (blockIdx.x / gn) * G2_BM, n0 = (blockIdx.x % gn) * G2_BN;
+  const int kt0 = blockIdx.y * kts;
+  const int nk = min(kts, nkt - kt0);
+  float* __restrict__ D = slab + (long)blockIdx.y * M * N;
+
+  // per-lane DMA sources: two A and two B instructions per wave per stage, each lane one 16-byte slot of a k row
+  long a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = wave * 128 + i * 64 + lane;
+    const int kr = p >> 5, ph = p & 31;
+    const int lg = ph ^ ((kr & 3) << 2);
+    a_off[i] = (long)(kt0 * G2_BK + kr) * lda + min(m0 + 8 * lg, M - 8);
+    b_off[i] = (long)(kt0 * G2_BK + kr) * ldb + min(n0 + 8 * lg, N - 8);
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) short*)lds;
+  auto issue = [&](int kt) {
+    const uint32_t st = lds_base + (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int slot0 = wave * 128 + i * 64;
+      const uint32_t dstA = __builtin_amdgcn_readfirstlane(st + slot0 * 16);
+      const uint32_t dstB = __builtin_amdgcn_readfirstlane(st + 16384 + slot0 * 16);
+      gb_dma16(A + a_off[i] + (long)kt * G2_BK * lda, dstA);
+      gb_dma16(B + b_off[i] + (long)kt * G2_BK * ldb, dstB);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (nk <= 0) return;
+  for (int s = 0; s < G2_ST - 1 && s < nk; ++s) issue(s);
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  uint32_t aA[4], aB[2];
+  {
+    const int kr = 8 * (tg >> 1) + tq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nc = wm0 + q * 32 + 16 * (tg & 1) + 4 * tp;
+      aA[q] = lds_base + (uint32_t)(2 * (kr * 256 + (((nc >> 3) ^ ((kr & 3) << 2)) << 3) + (nc & 7)));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int nc = wn0 + q * 32 + 16 * (tg & 1) + 4 * tp;
+      aB[q] = lds_base + 16384u + (uint32_t)(2 * (kr * 256 + (((nc >> 3) ^ ((kr & 3) << 2)) << 3) + (nc & 7)));
+    }
+  }
+#define KK_FRAG(dst, addr, O) do { v4s lo_ = g2_ldstr<O>(addr), hi_ = g2_ldstr<O + 2048>(addr); \
+    dst = (v8s){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]}; } while (0)
+  auto rd0 = [&](int kt, v8s (&a)[4], v8s (&b)[2]) {
+    const uint32_t so = (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+    KK_FRAG(a[0], aA[0] + so, 0); KK_FRAG(a[1], aA[1] + so, 0); KK_FRAG(a[2], aA[2] + so, 0); KK_FRAG(a[3], aA[3] + so, 0);
+    KK_FRAG(b[0], aB[0] + so, 0); KK_FRAG(b[1], aB[1] + so, 0);
+  };
+  auto rd1 = [&](int kt, v8s (&a)[4], v8s (&b)[2]) {
+    const uint32_t so = (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+    KK_FRAG(a[0], aA[0] + so, 8192); KK_FRAG(a[1], aA[1] + so, 8192); KK_FRAG(a[2], aA[2] + so, 8192);
+    KK_FRAG(a[3], aA[3] + so, 8192);
+    KK_FRAG(b[0], aB[0] + so, 8192); KK_FRAG(b[1], aB[1] + so, 8192);
+  };
+#undef KK_FRAG
+  auto mma = [&](const v8s (&a)[4], const v8s (&b)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[i]),
+                                                             __builtin_bit_cast(v8bf, b[j]), acc[i][j], 0, 0, 0);
+  };
+  // 12 transposing reads per half k-tile and wave
+  v8s a0[4], b0[2], a1[4], b1[2];
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  rd0(0, a0, b0);
+  int kt = 0;
+  for (; kt + G2_ST - 1 < nk; ++kt) {
+    rd1(kt, a1, b1);
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(kt + G2_ST - 1);
+    rd0(kt + 1, a0, b0);
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (; kt < nk; ++kt) {
+    rd1(kt, a1, b1);
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      rd0(kt + 1, a0, b0);
+      asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn0 + j * 32 + fr;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m < M) D[(long)m * N + n] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void kk_reduce_kernel(const float4* __restrict__ slab, long n4, int ns, float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = slab[i];
+  for (int z = 1; z < ns; ++z) {
+    const float4 v = slab[(long)z * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  out[i] = s;
+}
+
+static void kk_plan(int M, int N, long K, int& ns, int& kts) {
+  const int tiles = mo_cdiv(M, G2_BM) * mo_cdiv(N, G2_BN);
+  const int nkt = (int)(K / G2_BK);
+  ns = mo_cdiv(256, tiles);                           // one round of the 256 CUs
+  if (ns > nkt / 16) ns = nkt / 16 > 0 ? nkt / 16 : 1;  // at least 16 k-tiles per split
+  kts = mo_cdiv(nkt, ns);
+  ns = mo_cdiv(nkt, kts);
+}
+extern "C" long mo_wgrad_bf16_kk_ws_floats(int M, int N, long K) {
+  int ns, kts;
+  kk_plan(M, N, K, ns, kts);
+  return (long)ns * M * N;
+}
+// dW[M][N] = A^T B over K rows (fp32 result); ws: mo_wgrad_bf16_kk_ws_floats(M, N, K) floats
+extern "C" int mo_wgrad_bf16_kk(const void* A, int lda, const void* B, int ldb, long K, int M, int N, float* dW,
+                                float* ws, void* stream) {
+  MO_CHECK_ARG(A && B && dW && ws && M >= 8 && N >= 8 && K >= 32);
+  MO_CHECK_ARG((K % G2_BK) == 0 && (M % 8) == 0 && (N % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0);
+  MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)dW % 16) == 0 && ((long)M * N) % 4 == 0);
+  MO_CHECK_ARG(K / G2_BK < (1L << 30));
+  int ns, kts;
+  kk_plan(M, N, K, ns, kts);
+  dim3 grid(mo_cdiv(M, G2_BM) * mo_cdiv(N, G2_BN), ns);
+  hipLaunchKernelGGL(gemm_bf16_kk_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda, (const short*)B,
+                     ldb, ws, M, N, (int)(K / G2_BK), kts);
+  const long n4 = (long)M * N / 4;
+  hipLaunchKernelGGL(kk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)ws, n4, ns, (float4*)dW);
+  return mo_launch_status();
+}
+
 __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ x, int rows, int cols, unsigned short* __restrict__ y,
                                        int ld_out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

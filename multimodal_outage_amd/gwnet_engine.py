@@ -346,7 +346,7 @@ class GwnetFunction(torch.autograd.Function):
         ctx.layers, ctx.x_int, ctx.adp, ctx.adpT, ctx.skip, ctx.r1 = layers, x_int, adp, adpT, skip, r1
         ctx.adp_bf = adp_bf
         ctx.mfma_bf16 = int(use_bf)
-        ctx.W1_bf = W1_bf
+        ctx.W1_bf, ctx.skip_bf = W1_bf, skip_bf
         ctx.params = p
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -397,9 +397,19 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_conv1x1_bwd_data', L.ptr(dy_int), cfg.Cout, P_f, L.ptr(p['end_conv_2.weight']), cfg.Ce,
                    L.ptr(da1), 0, 0, 0, L.ptr(r1), 0, st)
         gW1 = gbuf('end_conv_1.weight', p['end_conv_1.weight']); gb1 = gbuf('end_conv_1.bias', p['end_conv_1.bias'])
-        lane.run(lambda: L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, P_f, L.ptr(skip), cfg.Cs, 0, 0, 0, 1,
-                                L.ptr(gW1), L.ptr(gb1), L.ptr(ws_for(cfg.Ce, cfg.Cs, P_f)), L.stream()),
-                 reads=(da1,))
+        if da1_bf is not None and ctx.skip_bf is not None and P_f % 32 == 0 and cfg.Ce % 8 == 0 and cfg.Cs % 8 == 0:
+            # both operands k-major bf16 as they lie: split-K ring GEMM; the bias gradient is an fp32 column sum
+            def _w1():
+                wsk = torch.empty(lib.mo_wgrad_bf16_kk_ws_floats(cfg.Ce, cfg.Cs, P_f), device=dev, dtype=torch.float32)
+                L.call('mo_wgrad_bf16_kk', L.ptr(da1_bf), cfg.Ce, L.ptr(ctx.skip_bf), cfg.Cs, P_f, cfg.Ce, cfg.Cs,
+                       L.ptr(gW1), L.ptr(wsk), L.stream())
+                wsc = torch.empty(lib.mo_colsum_ws_floats(P_f, cfg.Ce), device=dev, dtype=torch.float32)
+                L.call('mo_colsum', L.ptr(da1), P_f, cfg.Ce, L.ptr(gb1), L.ptr(wsc), L.stream())
+            lane.run(_w1, reads=(da1, da1_bf))
+        else:
+            lane.run(lambda: L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, P_f, L.ptr(skip), cfg.Cs, 0, 0, 0, 1,
+                                    L.ptr(gW1), L.ptr(gb1), L.ptr(ws_for(cfg.Ce, cfg.Cs, P_f)), L.stream()),
+                     reads=(da1,))
         dskip = _e(P_f, cfg.Cs, dev)
         if ctx.W1_bf is not None:
             # dskip = (da1 @ W1) gated by skip > 0: W1 (Ce, Cs) row-major is the [K][N] operand as it lies

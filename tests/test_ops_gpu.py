@@ -301,6 +301,38 @@ def test_linear_splitk(L, P, Ci, Co):
     close(din, dout @ W, what='linear split-K bwd data')
 
 
+@pytest.mark.parametrize('K,M,N', [(3200, 512, 256), (96, 64, 40), (32 * 70, 264, 520), (384000, 512, 256)])
+def test_wgrad_bf16_kk(L, K, M, N):
+    """Wide 1x1-conv weight gradient dW = A^T B with both bf16 operands k-major (end_conv_1 backward in the throughput
+    mode, graph_wavenet.py:174-177): exact products of bf16 inputs, fp32 accumulation, vs float64 on the same values."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    B = torch.randn(K, N, generator=g).to(torch.bfloat16)
+    Ad, Bd = A.cuda(), B.cuda()
+    dW = torch.empty(M, N, device='cuda')
+    ws = torch.empty(lib.mo_wgrad_bf16_kk_ws_floats(M, N, K), device='cuda')
+    L.call('mo_wgrad_bf16_kk', L.ptr(Ad), M, L.ptr(Bd), N, K, M, N, L.ptr(dW), L.ptr(ws), L.stream())
+    torch.cuda.synchronize()
+    if K > 100000:      # full head size: reference through chunks on the GPU in fp32 (fp32 accumulate both sides)
+        ref = torch.zeros(M, N, device='cuda', dtype=torch.float64)
+        for k0 in range(0, K, 32000):
+            ref += Ad[k0:k0 + 32000].double().t() @ Bd[k0:k0 + 32000].double()
+        ref = ref.cpu()
+    else:
+        ref = A.double().t() @ B.double()
+    err = float((dW.cpu().double() - ref).abs().max())
+    assert err <= 2e-5 * np.sqrt(K) * 4 + 1e-6, err       # fp32 accumulation of exact bf16 products
+    # ragged asymmetric check: a one-hot A picks rows of B exactly
+    if K <= 4000:
+        A1 = torch.zeros(K, M, dtype=torch.bfloat16); A1[7, 3] = 1.0; A1[K - 1, M - 1] = 1.0
+        L.call('mo_wgrad_bf16_kk', L.ptr(A1.cuda()), M, L.ptr(Bd), N, K, M, N, L.ptr(dW), L.ptr(ws), L.stream())
+        out = dW.cpu()
+        assert torch.equal(out[3], B[7].float()) and torch.equal(out[M - 1], B[K - 1].float())
+        out[3] = 0; out[M - 1] = 0
+        assert not out.any()
+
+
 def test_gemm_fragment_layout_asymmetric(L):
     """A = I with an ASYMMETRIC B: catches a transposed MFMA C-write (guide section 3)."""
     N, J = 128, 256
