@@ -5,7 +5,7 @@
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
-#define RED_STAGE 32   // stage-A width of the two-stage [nblk][64] -> [64] reductions
+#define RED_STAGE 256  // stage-A width of the two-stage [nblk][64] -> [64] reductions
 
 // ------------------------------------------------------------------------------------------------
 // GEMM launch helpers
@@ -203,9 +203,71 @@ __global__ void colsum_partial_kernel(const float* __restrict__ X, long P, int C
     __syncthreads();
   }
 }
-extern "C" long mo_colsum_ws_floats(long P, int C) { return (long)mo_cdiv(P, CS_ROWS) * C + 16; }
+// wide rows (C % 4 == 0): CSW_BLOCKS blocks stride over 32-row chunks with 16-byte loads, four chunks in flight;
+// the [CSW_BLOCKS][C] partials are summed by 32 slab lanes per column (fixed order => deterministic)
+#define CSW_BLOCKS 1024
+__global__ void __launch_bounds__(256) colsum_wide_kernel(const float4* __restrict__ X, long P, int C4,
+                                                          float4* __restrict__ part) {
+  __shared__ float4 sm[256];
+  const int RY = 256 / C4;                       // rows in flight per block pass (C4 <= 256, divides 256)
+  const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  const long step = (long)CSW_BLOCKS * RY;
+  long r = (long)blockIdx.x * RY + ty;
+  for (; r + 3 * step < P; r += 4 * step) {
+    const float4 a = X[r * C4 + tx], b = X[(r + step) * C4 + tx], c = X[(r + 2 * step) * C4 + tx],
+                 d = X[(r + 3 * step) * C4 + tx];
+    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+    s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+  }
+  for (; r < P; r += step) {
+    const float4 a = X[r * C4 + tx];
+    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+  }
+  s0.x += s1.x + (s2.x + s3.x); s0.y += s1.y + (s2.y + s3.y); s0.z += s1.z + (s2.z + s3.z); s0.w += s1.w + (s2.w + s3.w);
+  sm[threadIdx.x] = s0;
+  __syncthreads();
+  if (ty == 0) {
+    float4 t = sm[tx];
+    for (int y = 1; y < RY; ++y) { const float4 v = sm[y * C4 + tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    part[(long)blockIdx.x * C4 + tx] = t;
+  }
+}
+__global__ void __launch_bounds__(1024) slab_reduce32_kernel(const float* __restrict__ slab, long stride, int nz,
+                                                             float* __restrict__ out, long n) {
+  __shared__ float sm[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + tx;
+  float s = 0.f;
+  if (i < n)
+    for (int z = ty; z < nz; z += 32) s += slab[(long)z * stride + i];
+  sm[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) t += sm[q][tx];
+    out[i] = t;
+  }
+}
+static bool colsum_wide_ok(const float* X, const float* ws, long P, int C) {
+  return ((uintptr_t)ws % 16) == 0 && (C % 4) == 0 && C >= 4 && C <= 1024 && (256 % (C / 4)) == 0 && ((uintptr_t)X % 16) == 0 && P >= 4096;
+}
+extern "C" long mo_colsum_ws_floats(long P, int C) {
+  const long a = (long)mo_cdiv(P, CS_ROWS) * C, b = (long)CSW_BLOCKS * C;
+  return (a > b ? a : b) + 16;
+}
 extern "C" int mo_colsum(const float* X, long P, int C, float* out, float* ws, void* stream) {
   MO_CHECK_ARG(X && out && ws && P > 0 && C > 0);
+  if (colsum_wide_ok(X, ws, P, C)) {
+    hipLaunchKernelGGL(colsum_wide_kernel, dim3(CSW_BLOCKS), dim3(256), 0, ST(stream), (const float4*)X, P, C / 4,
+                       (float4*)ws);
+    hipLaunchKernelGGL(slab_reduce32_kernel, slab_grid(C), dim3(1024), 0, ST(stream), ws, (long)C, CSW_BLOCKS, out,
+                       (long)C);
+    return mo_launch_status();
+  }
   int nb = mo_cdiv(P, CS_ROWS);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, ST(stream), X, P, C, ws);
   hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(C), dim3(256), 0, ST(stream), ws, (long)C, nb, out,

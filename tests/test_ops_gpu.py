@@ -333,6 +333,19 @@ def test_wgrad_bf16_kk(L, K, M, N):
         assert not out.any()
 
 
+@pytest.mark.parametrize('P,C', [(384000, 512), (50000, 256), (4097, 64), (5000, 12), (300, 256)])
+def test_colsum(L, P, C):
+    """Bias gradients of the 1x1 convs are column sums over all rows (graph_wavenet.py:164,174-183 backward)."""
+    lib = L.load()
+    x = torch.randn(P, C, generator=torch.Generator().manual_seed(9))
+    xd = x.cuda()
+    out = torch.empty(C, device='cuda')
+    ws = torch.empty(lib.mo_colsum_ws_floats(P, C), device='cuda')
+    L.call('mo_colsum', L.ptr(xd), P, C, L.ptr(out), L.ptr(ws), L.stream())
+    ref = x.double().sum(0)
+    assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * np.sqrt(P) * 4
+
+
 def test_gemm_fragment_layout_asymmetric(L):
     """A = I with an ASYMMETRIC B: catches a transposed MFMA C-write (guide section 3)."""
     N, J = 128, 256
