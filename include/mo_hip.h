@@ -106,6 +106,13 @@ int mo_tcn_bwd(const float* h_prev, const float* scale, const float* shift, cons
 int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const float* vals, int n_rows,
                 const void* X, void* Y, long J, int beta, int x_bf16, int y_bf16 /* storage type of X / Y rows:
                 0 fp32, 1 bf16 (fp32 accumulation either way) */, void* stream);
+/* Blocked CSR for renumbered (clustered) nodes, bf16 rows: blocks of 16 consecutive output rows stage the DISTINCT
+ * source rows they need (their union, <= 64) in LDS once.  rowptr/vals: CSR of the matrix; lcol[e]: position of entry
+ * e's column in its block's union list; uptr[nb+1] / usrc[]: the unions (nb = ceil(n_rows/16)); max_union: the
+ * largest union (MO_EARG beyond 64: use mo_spmm_csr).  Same product as mo_spmm_csr (nconv, graph_wavenet.py:64-66). */
+int mo_spmm_blk(const int32_t* rowptr, const int32_t* lcol, const float* vals, const int32_t* uptr,
+                const int32_t* usrc, int n_rows, int max_union, const void* X_bf16, void* Y, long J, int beta,
+                int y_bf16, void* stream);
 /* dense support: Y[N][J] (+)= A_km^T @ X with A_km (N,N) row-major indexed [k][m]
  * (forward: A_km = adp; backward-data: A_km = adp^T). */
 int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, long J, int beta, void* stream);

@@ -1015,6 +1015,150 @@ extern "C" int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const f
   return mo_launch_status();
 }
 
+// ---- blocked CSR with per-block neighbour unions (throughput mode, bf16 rows) ---------------------------------
+// The plain CSR kernels above fetch every neighbour row of every output row from L2 (6 reads + 1 write of a row
+// piece per output piece): they run at the L2 -> CU rate, not at HBM's.  With the nodes renumbered so that 16
+// consecutive output rows are a compact cluster of the graph (host side: gwnet_engine.cluster_order), the 16 rows
+// share most of their neighbours: the block's DISTINCT source rows (its union, ~2.4 per output row on the k-NN
+// graphs of the benchmark) are staged once in LDS as 512-byte pieces and every output piece is combined from LDS.
+//   rowptr/vals: the CSR of the (renumbered) matrix; lcol[e]: position of entry e's column in its block's union;
+//   uptr[nb+1], usrc[]: the unions.  One workgroup = one block of SB_R rows x one 256-column piece.
+#define SB_R 16
+#define SB_UMAX 64
+__device__ __forceinline__ float sb_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float sb_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+template <bool YBF>
+__global__ void __launch_bounds__(256) spmm_blk_kernel(const int* __restrict__ rowptr, const int* __restrict__ lcol,
+                                                       const float* __restrict__ vals, const int* __restrict__ uptr,
+                                                       const int* __restrict__ usrc, int n, int nb,
+                                                       const unsigned short* __restrict__ X, void* __restrict__ Yv,
+                                                       long J, int nc, int nsplit, int beta) {
+  __shared__ uint4 tile[SB_UMAX * 32];                         // [union row][512 B]
+  const long bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const long idx = bid >> 3;
+  const int blk = (int)(idx % nb);
+  const int split = (int)(idx / nb);
+  // this workgroup's column pieces: xcd + 8*(split + nsplit*k) -- a piece stays on one XCD's L2, and the block's
+  // metadata (union, entries) is read once for all of them
+  const int cstride = 8 * nsplit;
+  int chunk = xcd + 8 * split;
+  if (chunk >= nc) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l5 = lane & 31;
+  const int u0 = uptr[blk], U = uptr[blk + 1] - u0;
+  const int r0 = blk * SB_R + wave * 4;                        // this wave's 4 output rows
+  const int rp = rowptr[min(r0 + min(lane, 4), n)];            // lanes 0..4 hold the 5 row pointers
+  int src[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int uu = wave * 2 + half + 8 * k;
+    src[k] = (uu < U) ? usrc[u0 + uu] : -1;
+  }
+  const int eb = __builtin_amdgcn_readlane(rp, 0), ee = __builtin_amdgcn_readlane(rp, 4);
+  const int myl0 = (eb + lane < ee) ? lcol[eb + lane] : 0;
+  const float myw0 = (eb + lane < ee) ? vals[eb + lane] : 0.f;
+  const uint2* t2 = reinterpret_cast<const uint2*>(tile);
+  auto fetch = [&](int c, uint4 (&v)[8]) {                      // the union's pieces of column chunk c -> registers
+    const long col8 = (long)c * 256 + 8 * l5;
+    const bool cv = col8 < J;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (src[k] >= 0 && cv) v[k] = *reinterpret_cast<const uint4*>(X + (long)src[k] * J + col8);
+    }
+  };
+  uint4 v[8];
+  fetch(chunk, v);
+  for (; chunk < nc; chunk += cstride) {
+    __syncthreads();                                           // everybody is done with the previous chunk's tile
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int uu = wave * 2 + half + 8 * k;
+      if (src[k] >= 0) tile[uu * 32 + l5] = v[k];
+    }
+    __syncthreads();
+    if (chunk + cstride < nc) fetch(chunk + cstride, v);       // in flight under this chunk's arithmetic
+    if (r0 >= n) continue;
+    const long col4 = (long)chunk * 256 + 4 * lane;
+    const bool ov = col4 < J;
+    float acc[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+      const int r = r0 + q;
+      if (beta && r < n && ov) {
+        if (YBF) {
+          const uint2 o = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(Yv) + (long)r * J + col4);
+          acc[q][0] = sb_lo(o.x); acc[q][1] = sb_hi(o.x); acc[q][2] = sb_lo(o.y); acc[q][3] = sb_hi(o.y);
+        } else {
+          const float4 o = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Yv) + (long)r * J + col4);
+          acc[q][0] = o.x; acc[q][1] = o.y; acc[q][2] = o.z; acc[q][3] = o.w;
+        }
+      }
+    }
+    for (int base = eb; base < ee; base += 64) {               // the wave's entries, 64 at a time in registers
+      int myl = myl0;
+      float myw = myw0;
+      if (base != eb) {
+        const int e = base + lane;
+        myl = (e < ee) ? lcol[e] : 0;
+        myw = (e < ee) ? vals[e] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int q0 = max(__builtin_amdgcn_readlane(rp, q), base);
+        const int q1 = min(__builtin_amdgcn_readlane(rp, q + 1), base + 64);
+        for (int k = q0; k < q1; ++k) {
+          const int li = __builtin_amdgcn_readlane(myl, k - base);
+          const float w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(myw), k - base));
+          const uint2 t = t2[li * 64 + lane];
+          acc[q][0] += w * sb_lo(t.x); acc[q][1] += w * sb_hi(t.x);
+          acc[q][2] += w * sb_lo(t.y); acc[q][3] += w * sb_hi(t.y);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + q;
+      if (r < n && ov) {
+        if (YBF)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(Yv) + (long)r * J + col4) =
+              make_uint2(spmm_pack2(acc[q][0], acc[q][1]), spmm_pack2(acc[q][2], acc[q][3]));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Yv) + (long)r * J + col4) =
+              make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+      }
+    }
+  }
+}
+extern "C" int mo_spmm_blk(const int32_t* rowptr, const int32_t* lcol, const float* vals, const int32_t* uptr,
+                           const int32_t* usrc, int n_rows, int max_union, const void* X_bf16, void* Y, long J,
+                           int beta, int y_bf16, void* stream) {
+  MO_CHECK_ARG(rowptr && lcol && vals && uptr && usrc && X_bf16 && Y && n_rows > 0 && J > 0 && (J % 8) == 0);
+  MO_CHECK_ARG(max_union >= 0 && max_union <= SB_UMAX);
+  MO_CHECK_ARG((((uintptr_t)X_bf16) & 15) == 0 && (((uintptr_t)Y) & 15) == 0);
+  const int nb = mo_cdiv(n_rows, SB_R);
+  const int nc = (int)((J + 255) / 256);
+  // column pieces per XCD, split so that the grid keeps >= ~16 workgroups per CU while a workgroup loops over
+  // several pieces (its metadata is read once and the next piece is prefetched under the current one)
+  const int per_xcd = mo_cdiv(nc, 8);
+  int nsplit = (int)mo_cdiv(4096L, 8L * nb);
+  if (nsplit > per_xcd) nsplit = per_xcd;
+  if (nsplit < 1) nsplit = 1;
+  const long nblk = 8L * nb * nsplit;
+  MO_CHECK_ARG(nblk < (1L << 31));
+  dim3 grid((unsigned)nblk), block(256);
+  if (y_bf16)
+    hipLaunchKernelGGL(spmm_blk_kernel<true>, grid, block, 0, ST(stream), rowptr, lcol, vals, uptr, usrc, n_rows, nb,
+                       (const unsigned short*)X_bf16, Y, J, nc, nsplit, beta);
+  else
+    hipLaunchKernelGGL(spmm_blk_kernel<false>, grid, block, 0, ST(stream), rowptr, lcol, vals, uptr, usrc, n_rows, nb,
+                       (const unsigned short*)X_bf16, Y, J, nc, nsplit, beta);
+  return mo_launch_status();
+}
+
 extern "C" int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, long J, int beta, void* stream) {
   MO_CHECK_ARG(A_km && X && Y && N > 0 && J > 0 && J < (1L << 31));
   MoOperand A = op_simple(A_km, N, N, N);        // KROWS: rows = k, cols = m

@@ -27,16 +27,95 @@ def csr_from_dense(a):
     return rowptr, cols.astype(np.int32), a[rows, cols].astype(np.float32)
 
 
+BLK_R, BLK_UMAX = 16, 64     # mo_spmm_blk: rows per block, largest neighbour union it stages (include/mo_hip.h)
+BLK_MIN_J = 16384            # below this row length the plain CSR kernel is as fast (measured, tools/bench_spmm.py)
+
+
+def cluster_order(patterns, R=BLK_R):
+    """Node renumbering for the blocked SpMM: order[new] = old.  Greedy clusters of R nodes grown breadth-first over
+    the union pattern of all supports (seeds in global BFS order), so that R consecutive rows share most neighbours
+    (k-NN graph of the benchmark: 36.9 distinct sources per 16 rows instead of 94.8 in file order)."""
+    pat = None
+    for a in patterns:
+        a = np.asarray(a) != 0
+        pat = (a | a.T) if pat is None else (pat | a | a.T)
+    n = pat.shape[0]
+    rows, cols = np.nonzero(pat)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    seen = np.zeros(n, dtype=bool)
+    bfs = []
+    for s0 in range(n):
+        if seen[s0]:
+            continue
+        seen[s0] = True
+        q, qi = [s0], 0
+        while qi < len(q):
+            v = q[qi]; qi += 1
+            for u in cols[rowptr[v]:rowptr[v + 1]]:
+                if not seen[u]:
+                    seen[u] = True
+                    q.append(int(u))
+        bfs.extend(q)
+    taken = np.zeros(n, dtype=bool)
+    order = []
+    for seed in bfs:
+        if taken[seed]:
+            continue
+        taken[seed] = True
+        cl, qi = [seed], 0
+        while len(cl) < R and qi < len(cl):
+            v = cl[qi]; qi += 1
+            for u in cols[rowptr[v]:rowptr[v + 1]]:
+                if not taken[u]:
+                    taken[u] = True
+                    cl.append(int(u))
+                    if len(cl) >= R:
+                        break
+        order.extend(cl)
+    return np.asarray(order, dtype=np.int64)
+
+
+def block_unions(rowptr, cols, n, R=BLK_R):
+    """Per block of R rows: the sorted distinct columns (usrc, uptr) and every entry's position in them (lcol)."""
+    nb = (n + R - 1) // R
+    uptr = np.zeros(nb + 1, dtype=np.int32)
+    usrc, lcol = [], np.zeros(len(cols), dtype=np.int32)
+    for b in range(nb):
+        lo, hi = int(rowptr[b * R]), int(rowptr[min(n, (b + 1) * R)])
+        u, inv = np.unique(cols[lo:hi], return_inverse=True)
+        usrc.append(u.astype(np.int32))
+        lcol[lo:hi] = inv
+        uptr[b + 1] = uptr[b] + len(u)
+    usrc = np.concatenate(usrc) if usrc else np.zeros(0, dtype=np.int32)
+    if len(usrc) == 0:
+        usrc = np.zeros(1, dtype=np.int32)
+    return lcol, uptr, usrc, int(np.max(np.diff(uptr))) if nb else 0
+
+
 class StaticSupport:
     """A static support A (N,N): CSR of A^T for the forward nconv (out[w] = sum_v A[v,w] x[v],
-    graph_wavenet.py:65) and CSR of A for its backward."""
+    graph_wavenet.py:65) and CSR of A for its backward.  With `order` (new -> old node) the matrix is renumbered
+    first and each CSR also carries its block-union form for mo_spmm_blk (None when a union exceeds BLK_UMAX)."""
 
-    def __init__(self, dense, device):
+    def __init__(self, dense, device, order=None):
         dense = np.asarray(dense, dtype=np.float32)
+        if order is not None:
+            dense = dense[np.ix_(order, order)]
         self.n = dense.shape[0]
-        self.fwd = tuple(torch.from_numpy(x).to(device) for x in csr_from_dense(dense.T))
-        self.bwd = tuple(torch.from_numpy(x).to(device) for x in csr_from_dense(dense))
+        self.fwd = self._pack(dense.T, device, order is not None)
+        self.bwd = self._pack(dense, device, order is not None)
         self.nnz = int(self.fwd[1].numel())
+
+    def _pack(self, a, device, blocked):
+        rowptr, cols, vals = csr_from_dense(a)
+        blk = None
+        if blocked:
+            lcol, uptr, usrc, umax = block_unions(rowptr, cols, self.n)
+            if umax <= BLK_UMAX:
+                blk = tuple(torch.from_numpy(x).to(device) for x in (lcol, uptr, usrc)) + (umax,)
+        return tuple(torch.from_numpy(x).to(device) for x in (rowptr, cols, vals)) + (blk,)
 
 
 def _e(n, w, dev):
@@ -187,6 +266,11 @@ class _WgradLane:
 
 def _spmm(csr, n, X, Y, J, beta):
     """Y (+)= S @ X over nbtc rows; the storage type of each side (fp32 / bf16) follows the tensors."""
+    blk = csr[3]
+    if blk is not None and X.dtype == torch.bfloat16 and J >= BLK_MIN_J:
+        L.call('mo_spmm_blk', L.ptr(csr[0]), L.ptr(blk[0]), L.ptr(csr[2]), L.ptr(blk[1]), L.ptr(blk[2]), n, blk[3],
+               L.ptr(X), L.ptr(Y), J, beta, int(Y.dtype == torch.bfloat16), L.stream())
+        return
     L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), n, L.ptr(X), L.ptr(Y), J, beta,
            int(X.dtype == torch.bfloat16), int(Y.dtype == torch.bfloat16), L.stream())
 

@@ -205,13 +205,27 @@ class gwnet(nn.Module):
         return names
 
     def _static_supports(self, device):
-        if self._statics is None or self._statics_dev != device:
+        """-> (supports, order, inverse): with static supports the nodes are renumbered by graph clusters so that the
+        blocked SpMM of the throughput mode (mo_spmm_blk) can share neighbour rows; order[new] = old node.  Both
+        numeric modes renumber, so the dropout mask (a function of seed and element index) is the same in both."""
+        key = device
+        if self._statics is None or self._statics_dev != key:
             sup = self.supports if self._use_gcn() else []
             if len(sup) * 2 + (2 if self.addaptadj else 0) + 1 > 8:
                 raise NotImplementedError('HIP gcn mlp supports at most 3 supports (incl. adaptive)')
-            self._statics = [StaticSupport(s, device) for s in sup]
-            self._statics_dev = device
-        return self._statics
+            order = None
+            if len(sup) > 0:
+                from ..gwnet_engine import cluster_order
+                order = cluster_order([np.asarray(a) for a in sup])
+            self._statics = [StaticSupport(a, device, order) for a in sup]
+            if order is not None:
+                inv = np.empty_like(order)
+                inv[order] = np.arange(len(order))
+                self._order = (torch.from_numpy(order).to(device), torch.from_numpy(inv).to(device))
+            else:
+                self._order = (None, None)
+            self._statics_dev = key
+        return self._statics, self._order[0], self._order[1]
 
     def body(self, x):
         """graph_wavenet.py:191-254 on a (B, in_dim, N, T) tensor -> (B, out_dim, N, T_final)."""
@@ -232,8 +246,21 @@ class gwnet(nn.Module):
         if self.training:
             for m in self.bn:
                 m.num_batches_tracked += 1
-        return GwnetFunction.apply(cfg, self._static_supports(x.device), bn_bufs, self.training,
-                                   x.float(), *params)
+        statics, order, inverse = self._static_supports(x.device)
+        x = x.float()
+        if order is not None:
+            # the engine works in the renumbered node space: input nodes and the node embeddings are gathered on the
+            # way in (their gradients return through autograd), the output is gathered back
+            x = x.index_select(2, order)
+            for k, name in enumerate(names):
+                if name == 'nodevec1':
+                    params[k] = params[k].index_select(0, order)
+                elif name == 'nodevec2':
+                    params[k] = params[k].index_select(1, order)
+            if cfg.grad_out is not None:
+                cfg.grad_out = {k: v for k, v in cfg.grad_out.items() if k not in ('nodevec1', 'nodevec2')}
+        y = GwnetFunction.apply(cfg, statics, bn_bufs, self.training, x, *params)
+        return y.index_select(2, inverse) if order is not None else y
 
     def forward(self, input):
         if input.dim() == 3:

@@ -346,6 +346,35 @@ def test_colsum(L, P, C):
     assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * np.sqrt(P) * 4
 
 
+@pytest.mark.parametrize('N,J,ybf,beta', [(300, 512, 1, 0), (300, 512, 0, 1), (77, 96, 1, 1), (3000, 1536, 1, 0),
+                                          (3000, 32 * 37, 0, 1)])
+def test_spmm_blocked_matches_csr(L, N, J, ybf, beta):
+    """Blocked-union SpMM of the renumbered graph (throughput mode) == the plain CSR SpMM on the same matrix
+    (nconv with a static support, graph_wavenet.py:64-66), bit for bit: same products, same order per row."""
+    from oracle import params as OP
+    from oracle import gwnet_ref
+    from multimodal_outage_amd.gwnet_engine import StaticSupport, cluster_order, _spmm
+    A = gwnet_ref.asym_adj(OP.knn_graph(N, seed=11))
+    A = A * (1.0 + 0.25 * np.sin(np.arange(N * N).reshape(N, N)))        # asymmetric values
+    order = cluster_order([A])
+    assert sorted(order.tolist()) == list(range(N))
+    sup = StaticSupport(A, 'cuda', order)
+    plain = StaticSupport(A[np.ix_(order, order)], 'cuda', None)
+    assert sup.fwd[3] is not None and sup.bwd[3] is not None and plain.fwd[3] is None
+    X = torch.randn(N, J, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+    for csr_b, csr_p in ((sup.fwd, plain.fwd), (sup.bwd, plain.bwd)):
+        y0 = torch.randn(N, J, generator=torch.Generator().manual_seed(2))
+        y0 = (y0.to(torch.bfloat16) if ybf else y0).cuda()
+        ya, yb = y0.clone(), y0.clone()
+        _spmm(csr_b, N, X, ya, J, beta)
+        _spmm(csr_p, N, X, yb, J, beta)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb)
+        ref = torch.from_numpy(A[np.ix_(order, order)].astype(np.float32)).double()
+        ref = (ref.t() if csr_b is sup.fwd else ref) @ X.cpu().double() + (y0.cpu().double() if beta else 0)
+        assert float((ya.cpu().double() - ref).abs().max()) <= (3e-2 if ybf else 1e-4) * max(1.0, float(ref.abs().max()))
+
+
 def test_gemm_fragment_layout_asymmetric(L):
     """A = I with an ASYMMETRIC B: catches a transposed MFMA C-write (guide section 3)."""
     N, J = 128, 256
