@@ -1,5 +1,5 @@
 """Turn two rocprofv3 counter-collection passes (FETCH_SIZE and WRITE_SIZE, collected SEPARATELY as
-MI355X_MICROARCH.md prescribes) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` into
+MI355X_MICROARCH.md prescribes) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-unet` into
   * a per-kernel table  profiles/<tag>_pmc_fetch_write_per_kernel.csv
   * the entry bench.py reads for roofline.traffic in profiles/r01_pmc_traffic.json (key <dtype>_b<batch>).
 
@@ -82,8 +82,8 @@ def main():
              "FETCH_SIZE_KB_per_launch_raw": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1),
              "algorithmic_bytes_per_launch_avg": int(alg / nl),
              "note": f"tools/pmc_summary.py over separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                     f"`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (batch {a.batch}, {a.dtype}); every "
-                     f"{a.match}* launch (incl. the 2 serial roofline steps and, in the throughput mode, the head's 2 GEMM launches per step; "
+                     f"`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-unet` (batch {a.batch}, {a.dtype}); every "
+                     f"{a.match}* launch (incl. the 2 serial roofline steps and, in the throughput mode, the head's 3 bf16 GEMM launches per step, one of them the split-K weight gradient; "
                      f"algorithmic_bytes_per_launch_avg covers the adjacency products); FETCH_SIZE x2 (gfx950 correction); "
                      f"per-kernel table {os.path.basename(out_csv)}"}
     jp = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
