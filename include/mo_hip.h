@@ -139,6 +139,11 @@ int mo_gemm_bf16_256_ex(const void* A, int lda, int a_kpad, const void* B, int l
                         int ldd, int M, int N, int K, int beta, void* D_bf16, const float* bias, int relu,
                         const float* mask, void* stream);
 
+/* Skip path backward, throughput mode (graph_wavenet.py:230-236): with the data gradients of all layers' skip convs
+ * computed by ONE product all[G*Tf][ld] = dskip x [Cs][32*L], add columns [col0, col0+32) of it to the last Tf time
+ * steps of a layer's dg rows: dg[g*Tout + Tout-Tf+t][c] += all[g*Tf+t][col0+c]. */
+int mo_skip_bwd_add(const float* all, int ld, int col0, long G, int Tf, int Tout, float* dg, void* stream);
+
 /* Weight gradient of a wide 1x1 conv (end_conv_1, graph_wavenet.py:174-177 backward) in the throughput mode:
  * dW[M][N] = A^T B over K rows with BOTH operands k-major as they lie in HBM (A: bf16 [K][M] output-gradient rows,
  * B: bf16 [K][N] input rows), split-K ring GEMM + fixed-order slab reduction.  K % 32 == 0; M, N, lda, ldb % 8 == 0. */

@@ -458,6 +458,32 @@ static int linear_splitk_plan(long P, int N, int K, int& nz, int& kchunk) {
   nz = (K + kchunk - 1) / kchunk;
   return nz;
 }
+// Skip path backward in the throughput mode: the data gradients of ALL layers' skip convs are one bf16 ring-GEMM
+// launch (dskip [G*Tf][Cs] x [Cs][32*L], mo_gemm_bf16_256); this adds layer `col0/32`'s 32 columns of that result to
+// the last Tf time steps of its dg rows (the crop of graph_wavenet.py:230-236 backwards).
+__global__ void skip_dg_add_kernel(const float4* __restrict__ all, int ld4, int col4, long rows, int Tf, int Tout,
+                                   float4* __restrict__ dg) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = i >> 3;
+  if (r >= rows) return;
+  const int c = (int)(i & 7);
+  const long g = r / Tf;
+  const int t = (int)(r - g * Tf);
+  const float4 v = all[r * ld4 + col4 + c];
+  float4* d = dg + (g * Tout + (Tout - Tf + t)) * 8 + c;
+  float4 o = *d;
+  o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+  *d = o;
+}
+extern "C" int mo_skip_bwd_add(const float* all, int ld, int col0, long G, int Tf, int Tout, float* dg, void* stream) {
+  MO_CHECK_ARG(all && dg && G > 0 && Tf > 0 && Tout >= Tf && ld >= col0 + 32 && col0 >= 0);
+  MO_CHECK_ARG((ld % 4) == 0 && (col0 % 4) == 0 && (((uintptr_t)all) & 15) == 0 && (((uintptr_t)dg) & 15) == 0);
+  const long rows = G * Tf;
+  hipLaunchKernelGGL(skip_dg_add_kernel, dim3((unsigned)mo_cdiv(rows * 8, 256)), dim3(256), 0, ST(stream),
+                     (const float4*)all, ld / 4, col0 / 4, rows, Tf, Tout, (float4*)dg);
+  return mo_launch_status();
+}
+
 extern "C" long mo_linear_splitk_ws_floats(long P, int N, int K) {
   int nz, kc; linear_splitk_plan(P, N, K, nz, kc);
   return (long)nz * P * N + 64;

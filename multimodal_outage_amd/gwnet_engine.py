@@ -495,10 +495,21 @@ class GwnetFunction(torch.autograd.Function):
                                     L.ptr(gW1), L.ptr(gb1), L.ptr(ws_for(cfg.Ce, cfg.Cs, P_f)), L.stream()),
                      reads=(da1,))
         dskip = _e(P_f, cfg.Cs, dev)
+        dg_skip = None        # throughput mode: [P_f][32*L] data gradients of all layers' skip convs, one product
         if ctx.W1_bf is not None:
             # dskip = (da1 @ W1) gated by skip > 0: W1 (Ce, Cs) row-major is the [K][N] operand as it lies
+            fuse_skip = cfg.Cs % 32 == 0 and (32 * cfg.L) % 8 == 0
+            dskip_bf = torch.empty((P_f, cfg.Cs), device=dev, dtype=torch.bfloat16) if fuse_skip else None
             L.call('mo_gemm_bf16_256_ex', L.ptr(da1_bf), cfg.Ce, cfg.Ce, L.ptr(ctx.W1_bf), cfg.Cs, 1, L.ptr(dskip), cfg.Cs,
-                   P_f, cfg.Cs, cfg.Ce, 0, None, None, 0, L.ptr(skip), st)
+                   P_f, cfg.Cs, cfg.Ce, 0, L.ptr(dskip_bf), None, 0, L.ptr(skip), st)
+            if fuse_skip:
+                # dg_i[crop] += dskip @ Ws_i for every layer i at once: Ws_i (Cs, 32) side by side is the [K][N] operand
+                Wcat = torch.cat([p[f'skip_convs.{i}.weight'].reshape(cfg.Cs, 32) for i in range(cfg.L)], dim=1)
+                Wcat_bf = torch.empty((cfg.Cs, 32 * cfg.L), device=dev, dtype=torch.bfloat16)
+                L.call('mo_f32_to_bf16', L.ptr(Wcat), L.ptr(Wcat_bf), Wcat.numel(), st)
+                dg_skip = _e(P_f, 32 * cfg.L, dev)
+                L.call('mo_gemm_bf16_256', L.ptr(dskip_bf), cfg.Cs, cfg.Cs, L.ptr(Wcat_bf), 32 * cfg.L, 1,
+                       L.ptr(dg_skip), 32 * cfg.L, P_f, 32 * cfg.L, cfg.Cs, 0, None, st)
         else:
             L.call('mo_conv1x1_bwd_data', L.ptr(da1), cfg.Ce, P_f, L.ptr(p['end_conv_1.weight']), cfg.Cs,
                    L.ptr(dskip), 0, 0, 0, L.ptr(skip), 0, st)
@@ -621,8 +632,11 @@ class GwnetFunction(torch.autograd.Function):
                 beta = 1
             # skip path (graph_wavenet.py:230-236): dg[crop] += dskip @ Ws ; dWs
             Ws = p[f'skip_convs.{i}.weight']
-            L.call('mo_conv1x1_bwd_data', L.ptr(dskip), cfg.Cs, P_f, L.ptr(Ws), 32, L.ptr(dg), Tf, Tout,
-                   Tout - Tf, None, beta, st)
+            if dg_skip is not None:
+                L.call('mo_skip_bwd_add', L.ptr(dg_skip), 32 * cfg.L, 32 * i, G, Tf, Tout, L.ptr(dg), st)
+            else:
+                L.call('mo_conv1x1_bwd_data', L.ptr(dskip), cfg.Cs, P_f, L.ptr(Ws), 32, L.ptr(dg), Tf, Tout,
+                       Tout - Tf, None, beta, st)
             gWs = gbuf(f'skip_convs.{i}.weight', Ws)
             lane.run(lambda g=g, gWs=gWs, Tout=Tout: L.call(
                 'mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,

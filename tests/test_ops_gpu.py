@@ -375,6 +375,20 @@ def test_spmm_blocked_matches_csr(L, N, J, ybf, beta):
         assert float((ya.cpu().double() - ref).abs().max()) <= (3e-2 if ybf else 1e-4) * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('G,Tf,Tout,Lc', [(120, 1, 12, 8), (37, 2, 5, 3), (64, 3, 3, 1)])
+def test_skip_bwd_add(L, G, Tf, Tout, Lc):
+    """Crop of the skip path backwards (graph_wavenet.py:230-236): layer i's 32 columns of the fused [G*Tf][32*L]
+    data-gradient product are added to the last Tf time steps of its dg rows; everything else is untouched."""
+    allg = rand(81, (G * Tf, 32 * Lc))
+    for i in range(Lc):
+        dg = rand(82 + i, (G * Tout, 32))
+        dgd = dev(dg)
+        L.call('mo_skip_bwd_add', L.ptr(dev(allg)), 32 * Lc, 32 * i, G, Tf, Tout, L.ptr(dgd), L.stream())
+        ref = dg.clone().view(G, Tout, 32)
+        ref[:, Tout - Tf:, :] += allg.view(G, Tf, 32 * Lc)[:, :, 32 * i:32 * i + 32]
+        assert torch.equal(dgd.cpu(), ref.view(G * Tout, 32))
+
+
 def test_gemm_fragment_layout_asymmetric(L):
     """A = I with an ASYMMETRIC B: catches a transposed MFMA C-write (guide section 3)."""
     N, J = 128, 256
