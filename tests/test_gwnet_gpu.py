@@ -112,6 +112,48 @@ def test_gwnet_vs_oracle_midsize():
         assert err <= 1e-3 * scale + 1e-7, (k, err, scale)
 
 
+def test_gwnet_flat_trainer_steps_follow_oracle_adam():
+    """Four optimizer steps of the product path (renumbered node space, gradients written into the flat buffer or
+    accumulated there by autograd for the node embeddings, fused Adam on the flat buffers) against the CPU oracle driven
+    by torch.optim.Adam(lr=1e-3) (lit.py:59-61) on the same seeded parameters and batch: the loss trajectory must agree
+    (each loss depends on every earlier update), and so must the parameters that received real gradients."""
+    from multimodal_outage_amd.trainer import FlatTrainer
+    cfg = dict(B=2, N=60, T=12, in_dim=8, out_dim=12, K=2, nsup=2, seed=930, knn=(60, 4))
+    sup = _supports(cfg)
+    m = _model(cfg, sup).train()
+    schema = P.gwnet_schema(num_nodes=60, supports_len=3, in_dim=8, out_dim=12, kernel_size=2)
+    p = P.as_param_dict(P.seeded_values(schema, 930))
+    tr = FlatTrainer(m, lr=1e-3)
+    m._mo_grad_out = tr.grad_out()
+    opt = torch.optim.Adam([v for v in p.values()], lr=1e-3)
+    x = rand(931, (2, 8, 60, 12))
+    tgt = None
+    sups = [torch.from_numpy(s) for s in sup]
+    for step in range(4):
+        opt.zero_grad()
+        yr = gwnet_ref.gwnet_forward(p, x, supports=sups, kernel_size=2)
+        if tgt is None:
+            tgt = rand(932, tuple(yr.shape))
+        lr_ = F.mse_loss(yr, tgt)
+        lr_.backward()
+        opt.step()
+        tr.zero_grad()
+        loss = F.mse_loss(m(x.cuda()), tgt.cuda())
+        loss.backward()
+        tr.allreduce()
+        tr.step()
+        lh, lo = float(loss.detach()), float(lr_.detach())
+        assert abs(lh - lo) <= 2e-4 * abs(lo), (step, lh, lo)
+    got = dict(m.named_parameters())
+    for k in ('start_conv.weight', 'end_conv_2.bias', 'gconv.2.mlp.mlp.weight', 'filter_convs.4.weight', 'bn.1.weight',
+              'skip_convs.6.weight', 'nodevec1', 'nodevec2'):
+        a, b = got[k].detach().cpu(), p[k].detach()
+        # an Adam step moves every coordinate by ~lr whatever the gradient's size, so coordinates whose gradient is at
+        # rounding level may legitimately differ by a few lr; the bulk must agree far below one step
+        d = (a - b).abs()
+        assert float(d.median()) <= 2e-5 and float((d > 5e-4).float().mean()) <= 0.02, (k, float(d.median()), float(d.max()))
+
+
 def test_gwnet_dropout_training_statistics():
     """dropout=0.3 (graph_wavenet.py:97): own counter-based mask; bitwise RNG parity with CPU torch is
     unattainable, so check determinism of backward w.r.t. the forward mask via a finite-difference
