@@ -205,8 +205,10 @@ extern "C" int mo_f32_to_bf16(const float* x, void* y, long n, void* stream) {
 // (LDS reads of the next 16 k in flight under the 8 MFMAs of the current 16 k, hand-counted lgkmcnt).
 // What bounds it (probes of round 1, J = 24576, bf16 result: DMA only 284 us, MFMA + LDS reads only 295 us, both
 // 419 us): the L2 -> LDS fill of 32 KB per k-tile and CU (about 53 GB/s per CU alone, less at the clock the MFMAs
-// leave) runs at the same pace as the 1024 MFMA cycles per k-tile -- a 256x256 tile is the largest accumulator two
-// waves per SIMD can hold, so this fill rate, not the matrix pipe, is the kernel's ceiling.
+// leave) runs at the same pace as the 1024 MFMA cycles per k-tile -- and the chip is power-limited under this kernel:
+// the shader clock drops from 2402 MHz (idle) to 1539 MHz beside it with random operands, 2174 MHz with an all-zero B
+// (tools/clock_probe), so matrix pipe, LDS reads and fill share one power budget and the ceiling is the 1.6 PF of the
+// sustained clock, not the 2.5 PF of the spec sheet.
 //   throughput model of the 128^2 kernel above: (bytes in flight per CU) x (flop per byte of the tile)
 //   / (L2/MALL latency) -- 64 KB x 64 flop/B / ~2.4 us x 256 CUs ~ 0.45 PF, which is what it measures.
 //   This kernel has 96 KB in flight at 128 flop/B.
