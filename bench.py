@@ -272,7 +272,9 @@ def main():
                 "avg_launch_gflop": round(gemm_flops / n_launch / 1e9, 3),
                 "note": "timed region: the product runs on a side stream beside the HBM-bound sparse branch and the "
                         "weight-gradient lane, so its launches are stretched by contention; *_serial = same launches "
-                        "with the overlap disabled (2 extra steps after the timed region)",
+                        "with the overlap disabled (2 extra steps after the timed region); peak is the spec-sheet dense "
+                        "bf16 figure at 2.4 GHz -- under this kernel the chip is power-limited and holds ~1.54 GHz "
+                        "(tools/clock_probe: 2402 MHz idle, 1539 MHz beside the GEMM), i.e. 1.6 PFLOP/s at the sustained clock",
                 "achieved_serial": round(ser_ach, 3), "frac_serial": round(ser_ach / peak, 4),
                 "avg_launch_ms_serial": round(ser_ms / max(len(prof_serial), 1), 4),
                 "traffic": pmc_traffic(args.dtype, B)}
