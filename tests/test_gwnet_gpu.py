@@ -154,6 +154,43 @@ def test_gwnet_flat_trainer_steps_follow_oracle_adam():
         assert float(d.median()) <= 2e-5 and float((d > 5e-4).float().mean()) <= 0.02, (k, float(d.median()), float(d.max()))
 
 
+def test_gwnet_directed_supports_vs_oracle():
+    """Two genuinely different, asymmetric supports (a directed graph and its reverse with unequal weights): the node
+    renumbering, the forward (A^T) and backward (A) CSR forms and their block-union variants must all agree with the
+    CPU oracle in the original node order -- outputs, input gradient and every parameter gradient (both modes)."""
+    N = 96
+    rng = np.random.RandomState(5)
+    A = P.knn_graph(N, seed=6).astype(np.float64)
+    A = A * (rng.rand(N, N) < 0.6) * (0.5 + rng.rand(N, N))            # drop 40 % of the directions, unequal weights
+    sup = [gwnet_ref.asym_adj(A).astype(np.float32), gwnet_ref.asym_adj(A.T).astype(np.float32)]
+    assert not np.allclose(sup[0], sup[1]) and not np.allclose(sup[0], sup[0].T)
+    cfg = dict(B=2, N=N, T=12, in_dim=8, out_dim=12, K=2, nsup=2, seed=940, knn=(N, 6))
+    schema = P.gwnet_schema(num_nodes=N, supports_len=3, in_dim=8, out_dim=12, kernel_size=2)
+    p = P.as_param_dict(P.seeded_values(schema, 940))
+    x = rand(941, (2, 8, N, 12))
+    xr = x.clone().requires_grad_(True)
+    yr = gwnet_ref.gwnet_forward(p, xr, supports=[torch.from_numpy(s_) for s_ in sup], kernel_size=2)
+    tgt = rand(942, tuple(yr.shape))
+    F.mse_loss(yr, tgt).backward()
+    for mode, tol_y, tol_g in (('f32', 1e-4, 1e-3), ('bf16', 2e-2, 1e-1)):
+        m = _model(cfg, sup).train()
+        m.dense_dtype = mode
+        xg = x.cuda().requires_grad_(True)
+        y = m(xg)
+        assert float((y.detach().cpu() - yr.detach()).abs().max()) <= tol_y * float(yr.abs().max()) + 1e-6, mode
+        F.mse_loss(y, tgt.cuda()).backward()
+        assert float((xg.grad.cpu() - xr.grad).abs().max()) <= tol_g * float(xr.grad.abs().max()) * 5 + 1e-7, mode
+        for k, v in m.named_parameters():
+            if p[k].grad is None:
+                continue
+            scale = float(p[k].grad.abs().max())
+            err = float((v.grad.cpu() - p[k].grad).abs().max())
+            # the node embeddings' gradient (a sum over all layers of products of bf16-rounded tensors pushed through
+            # the softmax) is the noisiest tensor of the throughput mode: 2e-1 of its scale here, 1e-1 for the rest
+            lim = 2 * tol_g if (mode == 'bf16' and k.startswith('nodevec')) else tol_g
+            assert err <= lim * scale + 1e-7, (mode, k, err, scale)
+
+
 def test_gwnet_dropout_training_statistics():
     """dropout=0.3 (graph_wavenet.py:97): own counter-based mask; bitwise RNG parity with CPU torch is
     unattainable, so check determinism of backward w.r.t. the forward mask via a finite-difference
