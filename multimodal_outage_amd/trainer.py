@@ -54,17 +54,20 @@ class FlatTrainer:
         self._span = {k: (o, o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN) for (k, p), o in zip(params, offs)}
         self._done = []          # [lo, hi) ranges already handed to an asynchronous all-reduce this step
         self._work = []
-        # buckets = top-level child modules; a bucket whose parameters have all received their gradient through
-        # autograd is announced from the post-accumulate hook of the last one (parameters an engine writes directly
-        # are announced by the engine itself through ready_callback, earlier than their hooks -- which this torch
-        # fires for every AccumulateGrad node of a finished Function, None gradients included -- would)
+        # buckets = top-level child modules, announced from the post-accumulate hook of the LAST parameter of the
+        # bucket that fires in a backward pass.  Which parameters fire is a property of the autograd graph, not of
+        # requires_grad (residual_convs.* with gcn on, gconv.7/bn.7 never enter it; this torch fires the hook of a
+        # finished Function's AccumulateGrad nodes even for None gradients), so the firing set of every bucket is
+        # LEARNED in the first backward pass (no hook-driven announcements there: the final pass of allreduce() covers
+        # everything) and every later pass re-arms from it.  Parameters an engine writes directly are announced by the
+        # engine itself through ready_callback, earlier than their hooks would.
         self._bucket = {k: k.split('.')[0] for k, _ in params}
-        self._bucket_names, self._bucket_total = {}, {}
+        self._bucket_names = {}
         for k, p in params:
             self._bucket_names.setdefault(self._bucket[k], []).append(k)
-            if p.requires_grad:
-                self._bucket_total[self._bucket[k]] = self._bucket_total.get(self._bucket[k], 0) + 1
-        self._bucket_left = dict(self._bucket_total)
+        self._expected = None        # {bucket: frozenset(names that fired in the previous backward pass)}
+        self._fired = {}             # {bucket: set(names fired in this backward pass)}
+        self._announced = set()      # buckets handed to mark_ready by the hooks in this backward pass
         if self.world > 1 and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
             for k, p in params:
                 if p.requires_grad:
@@ -88,9 +91,18 @@ class FlatTrainer:
 
     def _on_grad(self, k):
         b = self._bucket[k]
-        self._bucket_left[b] -= 1
-        if self._bucket_left[b] == 0:
-            self._bucket_left[b] = self._bucket_total[b]     # re-armed for the next backward pass
+        if b in self._announced:
+            # its bucket's all-reduce has started: this gradient would land beside / after the collective
+            raise RuntimeError(f'FlatTrainer: gradient of {k!r} arrived after bucket {b!r} was all-reduced (the set of '
+                               'parameters receiving gradients changed between steps, or backward ran twice before '
+                               'allreduce()); use FlatTrainer(overlap=False) for such a model')
+        fired = self._fired.setdefault(b, set())
+        fired.add(k)
+        if self._expected is None or not self.overlap:
+            return                               # first pass: learn the firing sets only
+        exp = self._expected.get(b)
+        if exp is not None and fired == exp:     # an unexpected name keeps the sets unequal -> final pass, re-learn
+            self._announced.add(b)
             self.mark_ready(self._bucket_names[b])
 
     def mark_ready(self, names):
@@ -125,6 +137,10 @@ class FlatTrainer:
         for w in self._work:
             w.wait()
         self._work, self._done = [], []
+        # re-arm every bucket for the next backward pass from what fired in this one
+        if self._fired:
+            self._expected = {b: frozenset(f) for b, f in self._fired.items()}
+        self._fired, self._announced = {}, set()
         return None
 
     def step(self):

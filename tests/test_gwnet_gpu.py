@@ -154,7 +154,7 @@ def test_gwnet_flat_trainer_steps_follow_oracle_adam():
         assert float(d.median()) <= 2e-5 and float((d > 5e-4).float().mean()) <= 0.02, (k, float(d.median()), float(d.max()))
 
 
-def test_gwnet_directed_supports_vs_oracle():
+def test_gwnet_directed_supports_vs_oracle(monkeypatch):
     """Two genuinely different, asymmetric supports (a directed graph and its reverse with unequal weights): the node
     renumbering, the forward (A^T) and backward (A) CSR forms and their block-union variants must all agree with the
     CPU oracle in the original node order -- outputs, input gradient and every parameter gradient (both modes)."""
@@ -172,9 +172,16 @@ def test_gwnet_directed_supports_vs_oracle():
     yr = gwnet_ref.gwnet_forward(p, xr, supports=[torch.from_numpy(s_) for s_ in sup], kernel_size=2)
     tgt = rand(942, tuple(yr.shape))
     F.mse_loss(yr, tgt).backward()
-    for mode, tol_y, tol_g in (('f32', 1e-4, 1e-3), ('bf16', 2e-2, 1e-1)):
+    from multimodal_outage_amd import gwnet_engine as E
+    for mode, tol_y, tol_g in (('f32', 1e-4, 1e-3), ('bf16', 2e-2, 1e-1), ('bf16-blk', 2e-2, 1e-1)):
         m = _model(cfg, sup).train()
-        m.dense_dtype = mode
+        m.dense_dtype = mode[:4].rstrip('-')
+        # 'bf16-blk': every static-support product through mo_spmm_blk (J = 2*T'*32 <= 768 is below the engine's
+        # switch-over length, so the route is forced by lowering it)
+        monkeypatch.setattr(E, 'BLK_MIN_J', 0 if mode == 'bf16-blk' else 1 << 40)
+        if mode == 'bf16-blk':
+            statics, _, _ = m._static_supports(torch.device('cuda', 0))
+            assert all(st.fwd[3] is not None and st.bwd[3] is not None for st in statics)
         xg = x.cuda().requires_grad_(True)
         y = m(xg)
         assert float((y.detach().cpu() - yr.detach()).abs().max()) <= tol_y * float(yr.abs().max()) + 1e-6, mode
@@ -355,3 +362,163 @@ def test_gwnet_supports_none_adaptive_only_vs_oracle():
         if p[k].grad is not None:
             s = float(p[k].grad.abs().max())
             assert float((v.grad.cpu() - p[k].grad).abs().max()) <= 1e-3 * s + 1e-7, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2 at its own size (N=3000, C=32, T=12, K=2, two directed static supports + adaptive): the oracle
+# needs a few seconds at B=2, so the HIP path is compared with it directly -- fp32 mode at the north star's 1e-4,
+# throughput (bf16) mode at its stated tolerance -- and the benchmark's batch of 256 is tied to the same oracle
+# run through a size-independent property (a batch of replicated windows).  VERDICT r1 #1(b,c), #2.
+# ------------------------------------------------------------------------------------------------------------------
+C2 = dict(B=2, N=3000, T=12, in_dim=32, out_dim=12, K=2, nsup=2, seed=960, knn=(3000, 0))
+
+
+@pytest.fixture(scope='module')
+def c2_oracle():
+    sup = _supports(C2)
+    schema = P.gwnet_schema(num_nodes=3000, supports_len=3, in_dim=32, out_dim=12, kernel_size=2)
+    p = P.as_param_dict(P.seeded_values(schema, C2['seed']))
+    x = rand(961, (2, 32, 3000, 12))
+    xr = x.clone().requires_grad_(True)
+    torch.set_num_threads(16)
+    yr = gwnet_ref.gwnet_forward(p, xr, supports=[torch.from_numpy(s_) for s_ in sup], kernel_size=2)
+    tgt = rand(962, tuple(yr.shape))
+    loss = F.mse_loss(yr, tgt)
+    loss.backward()
+    return dict(sup=sup, x=x, tgt=tgt, y=yr.detach(), loss=float(loss), dx=xr.grad,
+                grads={k: v.grad for k, v in p.items() if v.grad is not None},
+                nograd=[k for k, v in p.items() if v.requires_grad and v.grad is None])
+
+
+def _c2_check(m, y, xgrad, O, tol_y, tol_g, what):
+    ys = float(O['y'].abs().max())
+    assert float((y.detach().cpu() - O['y']).abs().max()) <= tol_y * ys, what
+    if xgrad is not None:
+        assert float((xgrad.cpu() - O['dx']).abs().max()) <= tol_g * float(O['dx'].abs().max()) + 1e-9, what
+    g = dict(m.named_parameters())
+    worst = (0.0, None)
+    for k, ref in O['grads'].items():
+        scale = float(ref.abs().max())
+        err = float((g[k].grad.cpu() - ref).abs().max())
+        lim = 2 * tol_g if (tol_g > 1e-2 and k.startswith('nodevec')) else tol_g
+        assert err <= lim * scale + 1e-7, (what, k, err, scale)
+        if scale > 0 and err / scale > worst[0]:
+            worst = (err / scale, k)
+    for k in O['nograd']:
+        assert g[k].grad is None or float(g[k].grad.abs().max()) == 0.0, k
+    return worst
+
+
+@pytest.mark.parametrize('mode,tol_y,tol_g', [('f32', 1e-4, 1e-3), ('bf16', 2e-2, 1e-1)])
+def test_gwnet_config2_full_size_vs_oracle(c2_oracle, mode, tol_y, tol_g):
+    """graph_wavenet.py:191-254 at N=3000: outputs, loss, input gradient and EVERY parameter gradient against the CPU
+    oracle.  fp32 mode: 1e-4 of the output scale / 1e-3 of each gradient's scale (north star); throughput mode: the
+    stated 2e-2 / 1e-1 (2e-1 for the node embeddings) against the ORACLE, not against its own fp32 mode."""
+    O = c2_oracle
+    m = _model(C2, O['sup']).train()
+    m.dense_dtype = mode
+    xg = O['x'].cuda().requires_grad_(True)
+    y = m(xg)
+    loss = F.mse_loss(y, O['tgt'].cuda())
+    assert abs(loss.item() - O['loss']) <= (1e-4 if mode == 'f32' else 1e-2) * O['loss']
+    loss.backward()
+    worst = _c2_check(m, y, xg.grad, O, tol_y, tol_g, mode)
+    print(f'config 2 full size, {mode}: worst gradient error {worst[0]:.2e} of scale ({worst[1]})')
+
+
+def test_gwnet_blocked_route_at_full_size(c2_oracle, monkeypatch):
+    """The engine's own routing to mo_spmm_blk (bf16 rows of >= BLK_MIN_J elements): N=3000, B=48 (J = 18432 at the
+    first layer).  (a) eval mode: the first two windows of the batch of 48 equal the batch of 2 (whose J = 768 rows take
+    the plain CSR kernel); (b) the same batch with the blocked kernel forced for every layer and with it disabled:
+    bit-identical outputs (the two kernels form the same products in the same order); (c) train mode with the blocked
+    kernel forced at B=2 still matches the oracle."""
+    from multimodal_outage_amd import gwnet_engine as E
+    O = c2_oracle
+    calls = []
+    real = E.L.call
+    monkeypatch.setattr(E.L, 'call', lambda name, *a: (calls.append(name), real(name, *a))[1])
+    m = _model(C2, O['sup']).eval()
+    m.dense_dtype = 'bf16'
+    x48 = torch.cat([O['x'], rand(963, (46, 32, 3000, 12))]).cuda()
+    with torch.no_grad():
+        y48 = m(x48)
+        routed = calls.count('mo_spmm_blk')
+        assert routed >= 4 and calls.count('mo_spmm_csr') > 0          # layer 0 blocked, short late layers plain
+        y2 = m(x48[:2])
+        monkeypatch.setattr(E, 'BLK_MIN_J', 0)
+        calls.clear()
+        y48_blk = m(x48)
+        assert calls.count('mo_spmm_csr') == 0 and calls.count('mo_spmm_blk') == 32
+        monkeypatch.setattr(E, 'BLK_MIN_J', 1 << 40)
+        calls.clear()
+        y48_csr = m(x48)
+        assert calls.count('mo_spmm_blk') == 0
+    assert torch.isfinite(y48).all()
+    assert torch.equal(y48_blk, y48_csr) and torch.equal(y48, y48_csr)
+    scale = float(y2.abs().max())
+    assert float((y48[:2] - y2).abs().max()) <= 1e-3 * scale
+    # (c) train mode, forward AND backward (CSR of A) through the blocked kernel, against the oracle
+    monkeypatch.setattr(E, 'BLK_MIN_J', 0)
+    m = _model(C2, O['sup']).train()
+    m.dense_dtype = 'bf16'
+    xg = O['x'].cuda().requires_grad_(True)
+    calls.clear()
+    y = m(xg)
+    F.mse_loss(y, O['tgt'].cuda()).backward()
+    assert calls.count('mo_spmm_blk') == 32 + 28 and calls.count('mo_spmm_csr') == 0
+    _c2_check(m, y, xg.grad, O, 2e-2, 1e-1, 'bf16 forced-blocked')
+
+
+def test_gwnet_bench_shape_b256_replicated_windows(c2_oracle):
+    """The benchmark's own shape: (256, 32, 3000, 12), throughput mode, dropout 0 -- 1.18 GB tensors, byte offsets
+    beyond 2^30, 9.2 M-row runs, the ring GEMM and mo_spmm_blk at J = 98304 inside the engine.  The batch is the
+    oracle fixture's two windows replicated 128 times: batch statistics of a replicated batch equal those of the two
+    windows, so every replica must reproduce the B=2 outputs, and the loss / every gradient of the mean-squared error
+    must equal the B=2 run's -- which test_gwnet_config2_full_size_vs_oracle ties to the CPU oracle."""
+    O = c2_oracle
+    m2 = _model(C2, O['sup']).train()
+    m2.dense_dtype = 'bf16'
+    y2 = m2(O['x'].cuda())
+    l2 = F.mse_loss(y2, O['tgt'].cuda())
+    l2.backward()
+    g2 = {k: v.grad.clone() for k, v in m2.named_parameters() if v.grad is not None}
+    y2 = y2.detach()
+    del m2
+    m = _model(C2, O['sup']).train()
+    m.dense_dtype = 'bf16'
+    x = O['x'].cuda().repeat(128, 1, 1, 1)
+    tgt = O['tgt'].cuda().repeat(128, 1, 1, 1)
+    assert x.shape == (256, 32, 3000, 12) and x.numel() * 4 > (1 << 30)
+    y = m(x)
+    assert tuple(y.shape) == (256, 12, 3000, 1) and torch.isfinite(y).all()
+    loss = F.mse_loss(y, tgt)
+    loss.backward()
+    scale = float(y2.abs().max())
+    yv = y.detach().view(128, 2, 12, 3000, 1)
+    # replicas agree with each other (first / middle / last: rows far beyond the 2^30-byte mark) and with the B=2 run
+    for r in (0, 63, 127):
+        assert float((yv[r] - yv[0]).abs().max()) <= 2e-3 * scale, r
+    assert float((yv[127] - y2).abs().max()) <= 1e-2 * scale
+    assert abs(loss.item() - l2.item()) <= 2e-3 * l2.item()
+    worst = (0.0, None)
+    for k, v in m.named_parameters():
+        if k not in g2:
+            continue
+        assert torch.isfinite(v.grad).all(), k
+        s = float(g2[k].abs().max())
+        e = float((v.grad - g2[k]).abs().max())
+        lim = 1e-1 if k.startswith('nodevec') else 5e-2
+        assert e <= lim * s + 1e-7, (k, e, s)
+        if s > 0 and e / s > worst[0]:
+            worst = (e / s, k)
+    print(f'B=256 replicated vs B=2: worst gradient distance {worst[0]:.2e} of scale ({worst[1]})')
+    # bf16-vs-oracle budget (1e-1 / 2e-1 of scale) covers the B=2 run's distance (test above) plus this one
+    _c2_check(m, yv[0], None, O, 3e-2, 1.5e-1, 'bf16 B=256 replicated')
+    # eval mode at the same batch: replicas are bit-identical functions of their window
+    m.eval()
+    with torch.no_grad():
+        ye = m(x).view(128, 2, 12, 3000, 1)
+        ye2 = m(x[:2])
+    assert torch.isfinite(ye).all()
+    assert float((ye[127] - ye2).abs().max()) <= 1e-3 * float(ye2.abs().max())
+    assert float((ye[64] - ye[0]).abs().max()) <= 1e-3 * float(ye2.abs().max())
