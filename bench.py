@@ -130,27 +130,34 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
 
     for _ in range(warmup):
         step()
-    # two timed passes of `steps` steps, the faster one reported: on a fresh box the first pass after the gwnet leg
-    # released its ~200 GB has been seen to take a multi-second allocator / driver stall (826 ms/step once, 24 ms
-    # otherwise); "passes" records both
-    passes = []
-    for _ in range(2):
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        sync()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        passes.append(dt)
-    dt = min(passes)
+    sync()
+    # ONE timed pass; every step also gets a host timestamp and a HIP event, so that a stall shows where it sits
+    # (launch side vs device side, which step) instead of disappearing in a best-of-N
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    host = [0.0] * (steps + 1)
+    ms0 = torch.cuda.memory_stats()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        loss = step()
+        ev[i + 1].record()
+        host[i + 1] = time.perf_counter() - t0
+    sync()
+    dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    step_gpu = [round(ev[i].elapsed_time(ev[i + 1]), 2) for i in range(steps)]
+    step_host = [round((host[i + 1] - host[i]) * 1e3, 2) for i in range(steps)]
+    trace = {"step_ms_gpu": step_gpu, "step_ms_host_launch": step_host,
+             "device_allocs_in_pass": int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),
+             "device_frees_in_pass": int(ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0))}
     tiles = batch * 67 * horizon
     return {"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(world * tiles * steps / dt, 1), "unit": "tiles/s",
             "ms_per_step": round(dt / steps * 1e3, 2), "tiles_per_step_per_gpu": tiles, "steps": steps, "warmup": warmup,
-            "passes_ms_per_step": [round(p / steps * 1e3, 2) for p in passes], "dtype": "f32", "data": "synthetic",
+            "trace": trace, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Modified_UNET fwd+MSE+bwd+Adam on ({batch},67,{horizon},{cin},{size},{size}) tiles",
                        "tile": f"{cin}x{size}x{size}", "counties": 67, "horizon": horizon, "parallelism": f"dp{world}"},
             "loss": round(float(loss.detach()), 5)}

@@ -173,7 +173,7 @@ class Modified_UNET(nn.Module):
             o = torch.cat((feat[b], time_dim[b].to(feat.dtype)), dim=-1)      # (67, H, 320)  unet.py:224
             zs.append(self.st_gnn(o))                            # (67, H, 256)
         z = torch.stack(zs).reshape(n, feature_vector_size)
-        st_d = dict(state, names=dec_names, skip_views=st_e['skip_views'],
+        st_d = dict(state, names=dec_names, skip_meta=st_e['skip_meta'],
                     fc_dropout=self.decoder.dropout1.p)
         out = UnetDecodeFn.apply(st_d, z, *fms, *[named[k] for k in dec_names])
         return out.view(B, NC, H, out.shape[1], S, S)

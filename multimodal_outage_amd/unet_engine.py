@@ -234,10 +234,20 @@ class UnetEncodeFn(torch.autograd.Function):
         L.call('mo_unet_act', L.ptr(v5.t), v5.istride, v5.C, n, v5.H, v5.W, L.ptr(v5.sc), L.ptr(v5.sh), gs, 0, L.ptr(x5a),
                v5.istride, st)
         fc_sv, feat = fc_block_fwd(p, 'encoder', x5a.view(n, -1), _drop_params(state['fc_dropout'], training))
-        state['skip_views'] = views[:4]
+        # the decoder needs the skip maps' folded BatchNorm affine; the maps themselves reach it as Function inputs
+        state['skip_meta'] = [(v.C, v.H, v.W, v.sc, v.sh) for v in views[:4]]
+        # tensors that are OUTPUTS of this Function must not be referenced from ctx attributes: output -> grad_fn ->
+        # ctx -> output is a reference cycle, the step's activations then live until Python's cyclic collector runs
+        # and the caching allocator has to grow (hipMalloc) in the middle of later steps -- the multi-second stall of
+        # round 1's UNet bench leg.  They go through save_for_backward and are put back in backward.
+        outs = (feat,) + tuple(v.t for v in views[:4])
+        ctx.save_for_backward(*outs)
+        fc_sv['h2'] = None
+        for k in range(4):
+            saved[k]['y2'] = None
         ctx.state, ctx.p, ctx.saved, ctx.fc_sv, ctx.n = state, p, saved, fc_sv, n
         ctx.x_needs_grad = x.requires_grad
-        return (feat,) + tuple(v.t for v in views[:4])
+        return outs
 
     @staticmethod
     def backward(ctx, dfeat, dfm1, dfm2, dfm3, dfm4):
@@ -245,7 +255,10 @@ class UnetEncodeFn(torch.autograd.Function):
         gs = state['gsize']
         dev = dfeat.device
         grads = {}
-        dx5a = fc_block_bwd(p, ctx.fc_sv, dfeat, grads)
+        outs = ctx.saved_tensors
+        fc_sv = dict(ctx.fc_sv, h2=outs[0])
+        saved = [dict(sv, y2=outs[1 + k]) if k < 4 else sv for k, sv in enumerate(saved)]
+        dx5a = fc_block_bwd(p, fc_sv, dfeat, grads)
         v5 = saved[4]
         dp = double_conv_bwd(p, saved[4], n, gs, grads, dev, da=dx5a.view(n, v5['Co'], v5['H'], v5['W']), dp=None)
         dfm = [dfm1, dfm2, dfm3, dfm4]
@@ -266,9 +279,9 @@ class UnetDecodeFn(torch.autograd.Function):
         gs, training, bufs = state['gsize'], state['training'], state['bufs']
         st = L.stream()
         fc_sv, h2 = fc_block_fwd(p, 'decoder', z.contiguous(), _drop_params(state['fc_dropout'], training))
-        S0 = state['skip_views'][3].H // 2
+        skips = [View(fm, *meta) for fm, meta in zip((fm1, fm2, fm3, fm4), state['skip_meta'])]
+        S0 = skips[3].H // 2
         v = View(h2.view(n, 64, S0, S0), 64, S0, S0)
-        skips = state['skip_views']
         ups = []
         for k, (ci, co) in enumerate(DEC_CH, 1):
             H = v.H

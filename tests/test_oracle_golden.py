@@ -185,6 +185,27 @@ def test_modified_unet_full():
     assert int(p['contraction.inc.double_conv.1.num_batches_tracked']) == 67 * 2
 
 
+def test_modified_unet_config3_forward():
+    """BASELINE config 3 shape: Modified_UNET on (1,67,2,13,256,256) tiles, FC bottleneck 16384->4096->256 (the
+    reference's Encoder/Decoder with image_dimension=256, unet.py:128-136,151-160): oracle forward + MSE against the
+    golden of the reference's own class bodies (the backward of this size is covered on the GPU box, where the HIP
+    path is checked against the same golden incl. gradients)."""
+    torch.set_num_threads(8)
+    G = golden('modified_unet_C3')
+    schema = P.unet_schema(input_channels=13, output_channels=13, image_dimension=256)
+    p = P.as_param_dict(P.seeded_values(schema, 410), requires_grad=False)
+    x = rand(411, (1, 67, 2, 13, 256, 256))
+    tdim = rand(413, (1, 67, 2, 64))
+    with torch.no_grad():
+        y = unet_ref.modified_unet_forward(p, x, tdim, horizon=2, supports=[torch.eye(67)])
+    assert tuple(y.shape) == tuple(G['y_shape'])
+    yn = y.numpy()
+    assert_close(yn.reshape(-1)[::997], G['y_sample'], 2e-5, 1e-4, 'y_sample')
+    assert_close(yn[-1, -1, -1, -1], G['y_last'], 2e-5, 1e-4)
+    loss = F.mse_loss(y, rand(412, tuple(y.shape)))
+    assert abs(loss.item() - float(G['loss'])) < 1e-5
+
+
 def test_metrics_restatement():
     y = rand(1, (5, 7))
     yh = rand(2, (5, 7))

@@ -12,29 +12,34 @@ from oracle import params as P
 pytestmark = pytest.mark.gpu
 
 
-def _model(seed=400, H=2):
+def _model(seed=400, H=2, channels=1, size=128):
     from multimodal_outage_amd.models.unet import Modified_UNET
-    m = Modified_UNET('gwnet', H, input_channels=1, output_channels=1)
-    P.load_into(m, P.seeded_values(P.unet_schema(), seed))
+    m = Modified_UNET('gwnet', H, input_channels=channels, output_channels=channels, image_dimension=size)
+    P.load_into(m, P.seeded_values(P.unet_schema(input_channels=channels, output_channels=channels,
+                                                 image_dimension=size), seed))
     m.st_gnn.dropout = 0.0
     m.encoder.dropout1.p = 0.0
     m.decoder.dropout1.p = 0.0
     return m.cuda()
 
 
-def test_modified_unet_vs_golden():
-    G = golden('modified_unet_B2H2')
-    m = _model().train()
-    x = rand(401, (2, 67, 2, 1, 128, 128)).cuda()
-    tdim = rand(403, (2, 67, 2, 64)).cuda()
+@pytest.mark.parametrize('name,B,channels,size,seed', [('modified_unet_B2H2', 2, 1, 128, 400),
+                                                       ('modified_unet_C3', 1, 13, 256, 410)])
+def test_modified_unet_vs_golden(name, B, channels, size, seed):
+    """unet.py:201-231 against the golden of the reference's own class bodies: the reference default shape (1x128x128
+    tiles) and BASELINE config 3 (13x256x256 tiles; Encoder/Decoder built for image_dimension=256, unet.py:128-136)."""
+    G = golden(name)
+    m = _model(seed, 2, channels, size).train()
+    x = rand(seed + 1, (B, 67, 2, channels, size, size)).cuda()
+    tdim = rand(seed + 3, (B, 67, 2, 64)).cuda()
     y = m(x, tdim)
     assert tuple(y.shape) == tuple(G['y_shape'])
     yn = y.detach().cpu().numpy()
     assert_close(yn.reshape(-1)[::997], G['y_sample'], 1e-4, 1e-4, 'y_sample')
     assert_close(yn[0, 0, 0, 0], G['y_first'], 1e-4, 1e-4, 'y_first')
-    assert_close(yn[-1, -1, -1, 0], G['y_last'], 1e-4, 1e-4, 'y_last')
+    assert_close(yn[-1, -1, -1, -1], G['y_last'], 1e-4, 1e-4, 'y_last')
     assert abs(float((yn.astype(np.float64) ** 2).sum()) - float(G['y_sqsum'])) < 1e-4 * float(G['y_sqsum'])
-    loss = F.mse_loss(y, rand(402, tuple(y.shape)).cuda())
+    loss = F.mse_loss(y, rand(seed + 2, tuple(y.shape)).cuda())
     assert abs(loss.item() - float(G['loss'])) < 1e-4 * float(G['loss'])
     loss.backward()
     grads = {k: v.grad for k, v in m.named_parameters()}
@@ -42,7 +47,7 @@ def test_modified_unet_vs_golden():
     for k, g in grads.items():
         assert (g is None or float(g.abs().max()) == 0.0) == (k in none), k
     worst = check_grads_vs_f64({k: g for k, g in grads.items() if g is not None}, G)
-    print('worst gradient error vs float64 reference (relative to tensor max):', worst)
+    print(name, 'worst gradient error vs float64 reference (relative to tensor max):', worst)
     check_grads(grads, G, atol=2e-6, rtol=1e-2, scale_rel=1e-2)      # and loosely against the fp32 golden
     sd = m.state_dict()
     for k in G.files:

@@ -126,12 +126,15 @@ def unet_blocks_case(seed=300):
     print('unet_blocks done')
 
 
-def modified_unet_case(name, B, H, seed):
+def modified_unet_case(name, B, H, seed, channels=1, size=128):
+    """Modified_UNET fwd + MSE + bwd through the reference's own class bodies (unet.py:201-231); `size` is the
+    module global image_dimension the reference's Encoder/Decoder read (unet.py:132-136,156-160), `channels` its
+    input_channels/output_channels constructor arguments (BASELINE config 3: 13 x 256 x 256 tiles)."""
     sup = [torch.eye(67)]
     ns_g = R.load_gwnet(False, sup)
-    ns = R.load_unet(ns_g['gwnet'])
-    m = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=1, output_channels=1)
-    schema = P.unet_schema()
+    ns = R.load_unet(ns_g['gwnet'], image_dimension=size)
+    m = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=channels, output_channels=channels)
+    schema = P.unet_schema(input_channels=channels, output_channels=channels, image_dimension=size)
     assert schema_of(m) == [(k, tuple(v)) for k, v in schema.items()], 'unet schema mismatch'
     P.load_into(m, P.seeded_values(schema, seed))
     m.st_gnn.dropout = 0.0
@@ -140,7 +143,7 @@ def modified_unet_case(name, B, H, seed):
     m.encoder.dropout1.p = 0.0
     m.decoder.dropout1.p = 0.0
     m.train()
-    x = rand(seed + 1, (B, 67, H, 1, 128, 128))
+    x = rand(seed + 1, (B, 67, H, channels, size, size))
     tdim = rand(seed + 3, (B, 67, H, 64))
     y = m(x, tdim)
     tgt = rand(seed + 2, tuple(y.shape))
@@ -150,13 +153,13 @@ def modified_unet_case(name, B, H, seed):
     d = dict(loss=np.float64(loss.item()), y_shape=np.array(yn.shape),
              y_sample=yn.reshape(-1)[::997].copy(), y_mean=np.float64(yn.mean()),
              y_sqsum=np.float64((yn.astype(np.float64) ** 2).sum()),
-             y_first=yn[0, 0, 0, 0].copy(), y_last=yn[-1, -1, -1, 0].copy(),
+             y_first=yn[0, 0, 0, 0].copy(), y_last=yn[-1, -1, -1, -1].copy(),
              seed=np.int64(seed))
     d.update(grad_summary(m, max_full=1100))
     d.update(buffers(m))
     # the same step in float64 (same class bodies): the yardstick for fp32 rounding noise of the
     # gradients, which are sums over millions of pixels with heavy cancellation
-    m64 = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=1, output_channels=1)
+    m64 = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=channels, output_channels=channels)
     P.load_into(m64, P.seeded_values(schema, seed))
     m64.st_gnn.dropout = 0.0
     for g in m64.st_gnn.gconv:
@@ -262,3 +265,6 @@ if __name__ == '__main__':
         date2vec_case()
     if 'unet' in which:
         modified_unet_case('modified_unet_B2H2', B=2, H=2, seed=400)
+    if 'unet_c3' in which:
+        # BASELINE config 3: 13-channel 256x256 tiles (FC bottleneck 16384 -> 4096 -> 256 -> 1024 -> 16384)
+        modified_unet_case('modified_unet_C3', B=1, H=2, seed=410, channels=13, size=256)
