@@ -260,6 +260,26 @@ int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint32_t thresh,
 /* ReLU backward on a materialised activation y: out = (y > 0) ? dy : 0 (fc layers, unet.py:142-144) */
 int mo_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream);
 
+/* ---- data-parallel exchange step: gradient all-reduce over RCCL / xGMI ---------------------------------
+ * Replaces Lightning's implicit DDP(NCCL) gradient all-reduce (lit.py:204; the reference has no explicit distributed
+ * code).  One communicator per process (= per GPU).  Rank 0 calls mo_allreduce_unique_id and hands the 128 bytes to
+ * every rank by any host channel; every rank then calls mo_allreduce_init.  mo_allreduce_launch sums buf[0..n) over
+ * all ranks IN PLACE on the communicator's own HIP stream, ordered by an event behind everything already queued on
+ * producer_stream, and returns at once (the collective runs beside the rest of backward); mode 0 = one all-reduce,
+ * mode 1 = reduce-scatter + all-gather (n % world == 0).  mo_allreduce_wait orders consumer_stream behind all
+ * collectives launched so far (no host wait).  The handle is the library's only state. */
+int mo_allreduce_unique_id(void* id128);
+int mo_allreduce_init(const void* id128, int rank, int world, void** handle);
+int mo_allreduce_launch(void* handle, float* buf, long n, int mode, void* producer_stream);
+int mo_allreduce_wait(void* handle, void* consumer_stream);
+int mo_allreduce_destroy(void* handle);
+
+/* ---- static supports: CSR of a dense HOST matrix (load_adj / asym_adj outputs, graph_wavenet.py:13-32,
+ * utils.py:152-158), rows ascending, columns ascending within a row (bit-exact vs scipy.sparse.csr_matrix).
+ * First call with colidx = vals = NULL fills rowptr[n_rows+1] and *nnz; second call fills colidx/vals. */
+int mo_csr_from_dense(const float* dense_host, int n_rows, int n_cols, int32_t* rowptr, int32_t* colidx,
+                      float* vals, long* nnz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,13 @@ SIGNATURES = {
     'mo_nchw_channel_sum': (i32, [vp, i64, i32, i64, i32, vp, vp, vp]),
     'mo_dropout': (i32, [vp, vp, i64, u32, u32, f32, vp]),
     'mo_relu_bwd': (i32, [vp, vp, vp, i64, vp]),
+    # ---- RCCL exchange step / host CSR builder
+    'mo_allreduce_unique_id': (i32, [vp]),
+    'mo_allreduce_init': (i32, [vp, i32, i32, C.POINTER(vp)]),
+    'mo_allreduce_launch': (i32, [vp, vp, i64, i32, vp]),
+    'mo_allreduce_wait': (i32, [vp, vp]),
+    'mo_allreduce_destroy': (i32, [vp]),
+    'mo_csr_from_dense': (i32, [vp, i32, i32, vp, vp, vp, C.POINTER(i64)]),
 }
 
 

@@ -19,12 +19,17 @@ from . import _lib as L
 def csr_from_dense(a):
     """Row-major CSR (rowptr, colidx int32; vals float32) of a dense matrix: the same ordering as
     scipy.sparse.csr_matrix(a) (rows ascending, columns ascending within a row)."""
-    a = np.asarray(a, dtype=np.float32)
-    rows, cols = np.nonzero(a)
-    rowptr = np.zeros(a.shape[0] + 1, dtype=np.int32)
-    np.add.at(rowptr, rows + 1, 1)
-    rowptr = np.cumsum(rowptr).astype(np.int32)
-    return rowptr, cols.astype(np.int32), a[rows, cols].astype(np.float32)
+    import ctypes as C
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    n, m = a.shape
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    nnz = C.c_long(0)
+    L.call('mo_csr_from_dense', a.ctypes.data, n, m, rowptr.ctypes.data, None, None, C.byref(nnz))
+    cols = np.zeros(max(nnz.value, 1), dtype=np.int32)
+    vals = np.zeros(max(nnz.value, 1), dtype=np.float32)
+    L.call('mo_csr_from_dense', a.ctypes.data, n, m, rowptr.ctypes.data, cols.ctypes.data, vals.ctypes.data,
+           C.byref(nnz))
+    return rowptr, cols[:nnz.value], vals[:nnz.value]
 
 
 BLK_R, BLK_UMAX = 16, 64     # mo_spmm_blk: rows per block, largest neighbour union it stages (include/mo_hip.h)

@@ -25,12 +25,40 @@ _ALIGN = 64   # floats (256 B): every parameter starts on a 16-byte boundary for
 
 
 class FlatTrainer:
-    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap=True):
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap=True,
+                 force_collectives=False, collective='allreduce', comm='torch'):
         self.module = module
         self.overlap = overlap   # False: nothing starts inside backward, allreduce() reduces the whole buffer
         self.lr, self.betas, self.eps = lr, betas, eps
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # collectives run when there is more than one rank -- or when forced (a world_size-1 RCCL communicator on a
+        # one-GPU box exercises librccl, the asynchronous handles and the stream ordering; tests/test_rccl_gpu.py)
+        self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
+        # 'allreduce': one ncclAllReduce per bucket.  'rs_ag': reduce-scatter + all-gather of the bucket (SURVEY 8e:
+        # on the fully connected xGMI mesh each rank then exchanges its 1/world shard with every peer over its own
+        # link instead of walking a ring); RCCL backend only (gloo has no reduce-scatter).
+        assert collective in ('allreduce', 'rs_ag')
+        self.collective = collective
+        # comm='torch': torch.distributed collectives on `process_group` (backend "nccl" = RCCL).  comm='abi': the
+        # library's own RCCL communicator (include/mo_hip.h mo_allreduce_*: the collective runs on its own HIP stream,
+        # ordered by events behind the producing stream and in front of the Adam kernel); torch.distributed is then
+        # only the host channel that hands rank 0's unique id to the other ranks.
+        assert comm in ('torch', 'abi')
+        self.comm = comm
+        self._abi = None
+        if comm == 'abi' and self.collectives:
+            import ctypes as C
+            ident = [None]
+            if dist.get_rank(process_group) == 0:
+                raw = C.create_string_buffer(128)
+                L.call('mo_allreduce_unique_id', raw)
+                ident = [raw.raw]
+            dist.broadcast_object_list(ident, src=0, group=process_group)
+            h = C.c_void_p()
+            L.call('mo_allreduce_init', C.create_string_buffer(ident[0], 128), dist.get_rank(process_group),
+                   self.world, C.byref(h))
+            self._abi = h
         params = [(k, p) for k, p in module.named_parameters()]
         dev = params[0][1].device
         offs, total = [], 0
@@ -68,7 +96,7 @@ class FlatTrainer:
         self._expected = None        # {bucket: frozenset(names that fired in the previous backward pass)}
         self._fired = {}             # {bucket: set(names fired in this backward pass)}
         self._announced = set()      # buckets handed to mark_ready by the hooks in this backward pass
-        if self.world > 1 and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
+        if self.collectives and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
             for k, p in params:
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(lambda _p, k=k: self._on_grad(k))
@@ -105,10 +133,26 @@ class FlatTrainer:
             self._announced.add(b)
             self.mark_ready(self._bucket_names[b])
 
+    def _reduce(self, lo, hi):
+        """Asynchronous sum over ranks of flat_g[lo:hi]; returns the handles to wait for."""
+        buf = self.flat_g[lo:hi]
+        rs = not (self.collective == 'allreduce' or (hi - lo) % self.world != 0 or (hi - lo) < 65536)
+        if self._abi is not None:
+            L.call('mo_allreduce_launch', self._abi, buf.data_ptr(), hi - lo, int(rs), L.stream())
+            return []
+        if not rs:
+            return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)]
+        n = (hi - lo) // self.world
+        rank = dist.get_rank(self.pg)
+        shard = buf[rank * n:(rank + 1) * n]          # reduced in place into this rank's slice, then gathered
+        w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        w2 = dist.all_gather_into_tensor(buf, shard, group=self.pg, async_op=True)   # same communicator: ordered
+        return [w1, w2]
+
     def mark_ready(self, names):
         """Start the all-reduce of the flat-gradient ranges covering `names` (maximal runs of adjacent parameters);
         call on the stream the gradients were produced on.  No-op for a single process."""
-        if self.world <= 1 or not self.overlap:
+        if not self.collectives or not self.overlap:
             return
         spans = sorted(self._span[k] for k in names if k in self._span)
         runs = []
@@ -120,22 +164,23 @@ class FlatTrainer:
         for lo, hi in runs:
             if any(lo < dhi and dlo < hi for dlo, dhi in self._done):
                 continue                     # (part of) the run was announced before: leave it to the final pass
-            self._work.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._work += self._reduce(lo, hi)
             self._done.append((lo, hi))
 
     def allreduce(self, async_op=False):
         """Reduce every range not announced through mark_ready, then wait for the asynchronous buckets."""
-        if self.world <= 1:
+        if not self.collectives:
             return None
         done = sorted(self._done)
         pos = 0
         for lo, hi in done + [(self.total, self.total)]:
             if lo > pos:
-                self._work.append(dist.all_reduce(self.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.pg,
-                                                  async_op=True))
+                self._work += self._reduce(pos, lo)
             pos = max(pos, hi)
         for w in self._work:
             w.wait()
+        if self._abi is not None:
+            L.call('mo_allreduce_wait', self._abi, L.stream())
         self._work, self._done = [], []
         # re-arm every bucket for the next backward pass from what fired in this one
         if self._fired:
@@ -154,6 +199,12 @@ class FlatTrainer:
 
     def set_lr(self, lr):
         self.lr = lr
+
+    def close(self):
+        """Release the library's RCCL communicator (comm='abi')."""
+        if self._abi is not None:
+            L.call('mo_allreduce_destroy', self._abi)
+            self._abi = None
 
 
 def cosine_lr(base_lr, epoch, t_max=10, eta_min=0.0):

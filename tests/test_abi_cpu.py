@@ -74,12 +74,8 @@ def test_state_dict_schema_matches_reference():
     assert [(k, tuple(v.shape)) for k, v in g.state_dict().items()] == \
         [(k, tuple(v)) for k, v in P.gwnet_schema(num_nodes=20, supports_len=3, in_dim=2, out_dim=12,
                                                     kernel_size=2).items()]
-    # same default initialisation stream as the reference constructors (same RNG consumption order)
-    torch.manual_seed(0)
-    a = gwnet('cpu')
-    torch.manual_seed(0)
-    b = gwnet('cpu')
-    assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
+    # (RNG consumption order of the constructor vs the reference's: tests/test_checkpoint_cpu.py, against the
+    # reference class's own initial values)
 
 
 def test_aptinit_svd_initialisation():

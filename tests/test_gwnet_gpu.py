@@ -529,3 +529,39 @@ def test_gwnet_bench_shape_b256_replicated_windows(c2_oracle):
     assert torch.isfinite(ye).all()
     assert float((ye[127] - ye2).abs().max()) <= 1e-3 * float(ye2.abs().max())
     assert float((ye[64] - ye[0]).abs().max()) <= 1e-3 * float(ye2.abs().max())
+
+
+def test_resume_from_reference_lightning_checkpoint():
+    """SURVEY 8(f) rank 2 (lit.py:59-72,187-196): the Lightning-shaped checkpoint of a reference run (weights with the
+    'model.st_gnn.' prefix, torch.optim.Adam state after 3 steps, CosineAnnealingLR after one epoch;
+    tests/golden/gwnet_ckpt.npz) is loaded into the product + FlatTrainer; the 4th step on the GPU must give the
+    reference's 4th-step output, loss and updated parameters."""
+    from test_checkpoint_cpu import lightning_ckpt, _product_gwnet
+    from multimodal_outage_amd.checkpoint import load_lightning_state
+    from multimodal_outage_amd.trainer import FlatTrainer
+    G = golden('gwnet_ckpt')
+    ckpt, _ = lightning_ckpt(G)
+    m = _product_gwnet().cuda().train()
+    tr = FlatTrainer(m)
+    m._mo_grad_out = tr.grad_out()
+    info = load_lightning_state(ckpt, m, tr, prefix='model.st_gnn.')
+    assert info['step'] == 3
+    seed = int(G['seed'])
+    x = rand(seed + 13, (3, 2, 20, 12)).cuda()
+    tgt = rand(seed + 53, (3, 12, 20, 1)).cuda()
+    assert abs(tr.lr - float(G['opt/lr'])) < 1e-12        # the scheduler's value for epoch 1 drives the 4th step
+    tr.zero_grad()
+    y = m(x)
+    loss = F.mse_loss(y, tgt)
+    loss.backward()
+    tr.allreduce()
+    tr.step()
+    assert_close(y, G['y4'], 1e-4, 1e-4, 'y of the resumed step')
+    assert abs(loss.item() - float(G['loss4'])) < 1e-4 * float(G['loss4'])
+    for k, v in m.named_parameters():
+        ref = G['p4/' + k]
+        got = v.detach().cpu().numpy()
+        if got.size > 4096:
+            got = got.reshape(-1)[::max(1, got.size // 2048)][:2048]
+        # one Adam step of size lr ~ 1e-3: parameters must agree to a small fraction of that step
+        assert_close(got, ref, 2e-5, 1e-5, 'param after resumed step ' + k)

@@ -184,6 +184,71 @@ def modified_unet_case(name, B, H, seed, channels=1, size=128):
     print(name, 'loss', loss.item(), 'loss64', loss64.item())
 
 
+def checkpoint_case(name='gwnet_ckpt', seed=1234):
+    """A Lightning-shaped checkpoint of the reference's own gwnet class (lit.py:59-72,187-196): default-initialised
+    under torch.manual_seed (so the init values pin the constructor's RNG consumption order), trained 3 steps with
+    torch.optim.Adam(lr=1e-3) + CosineAnnealingLR(T_max=10) stepped once; then the 4th step's output, loss and
+    updated parameters, which a resumed run must reproduce."""
+    N, in_dim, out_dim, K = 20, 2, 12, 2
+    A20 = P.knn_graph(20)
+    sup_t = [torch.from_numpy(asym_adj(A20)), torch.from_numpy(asym_adj(A20.T))]
+    ns = R.load_gwnet(True, sup_t, n_counties=N)
+    torch.manual_seed(seed)
+    g = ns['gwnet']('cpu', num_nodes=N, dropout=0.0, supports=sup_t, in_dim=in_dim, out_dim=out_dim, kernel_size=K,
+                    skip_channels=64, end_channels=128)
+    d = {'seed': np.int64(seed)}
+    for k, v in g.state_dict().items():
+        d['init/' + k] = v.detach().numpy().copy()
+    names = [k for k, _ in g.named_parameters()]
+    opt = torch.optim.Adam(g.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
+    g.train()
+
+    def step(i):
+        x = rand(seed + 10 + i, (3, in_dim, N, 12))
+        tgt = rand(seed + 50 + i, (3, out_dim, N, 1))
+        opt.zero_grad(set_to_none=True)
+        y = g(x)
+        loss = F.mse_loss(y, tgt)
+        loss.backward()
+        opt.step()
+        return y.detach().numpy().copy(), float(loss)
+
+    for i in range(3):
+        step(i)
+    sched.step()                                     # end of "epoch 0" (interval 'epoch', lit.py:66-71)
+    for k, v in g.state_dict().items():
+        d['sd/' + k] = v.detach().numpy().copy()
+    osd = opt.state_dict()
+    d['opt/lr'] = np.float64(osd['param_groups'][0]['lr'])
+    d['opt/initial_lr'] = np.float64(osd['param_groups'][0]['initial_lr'])
+    d['opt/has_state'] = np.array([int(i in osd['state']) for i in range(len(names))])
+    for i, k in enumerate(names):
+        if i in osd['state']:
+            st = osd['state'][i]
+            d['opt/exp_avg/' + k] = st['exp_avg'].numpy().copy()
+            d['opt/exp_avg_sq/' + k] = st['exp_avg_sq'].numpy().copy()
+            d['opt/step/' + k] = np.float64(float(st['step']))
+    d['sched/last_epoch'] = np.int64(sched.state_dict()['last_epoch'])
+    y4, l4 = step(3)
+    d['y4'] = y4
+    d['loss4'] = np.float64(l4)
+    for k, v in g.named_parameters():
+        d['p4/' + k] = v.detach().numpy().copy() if v.numel() <= 4096 else \
+            v.detach().numpy().reshape(-1)[::max(1, v.numel() // 2048)][:2048].copy()
+    # the scheduler's values for the first 25 epochs (configure_optimizers, lit.py:61)
+    o2 = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    s2 = torch.optim.lr_scheduler.CosineAnnealingLR(o2, T_max=10)
+    lrs = []
+    for _ in range(25):
+        lrs.append(o2.param_groups[0]['lr'])
+        o2.step()
+        s2.step()
+    d['cosine_lrs'] = np.array(lrs, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'loss4', l4, 'lr', d['opt/lr'])
+
+
 def csr_case():
     import pandas as pd
     import scipy.sparse as sp
@@ -257,6 +322,8 @@ if __name__ == '__main__':
                    seed=240, addaptadj=False)
         gwnet_case('gwnet_V_k1', B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, static_supports=sup2, generic=True,
                    seed=250)
+    if 'ckpt' in which:
+        checkpoint_case()
     if 'blocks' in which:
         unet_blocks_case()
     if 'csr' in which:
