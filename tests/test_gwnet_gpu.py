@@ -563,5 +563,11 @@ def test_resume_from_reference_lightning_checkpoint():
         got = v.detach().cpu().numpy()
         if got.size > 4096:
             got = got.reshape(-1)[::max(1, got.size // 2048)][:2048]
+        if k.startswith('gconv.') and k.endswith('.bias'):
+            # a bias in front of a BatchNorm: its true gradient is zero, what reaches Adam is the rounding noise of the
+            # implementation (~1e-9), and Adam's normalisation turns noise of ANY size into steps of up to lr -- the
+            # reference's own values are noise-driven here; bound: within one step of lr of each other
+            assert float(np.abs(got - ref).max()) <= 1.1 * float(G['opt/lr']), k
+            continue
         # one Adam step of size lr ~ 1e-3: parameters must agree to a small fraction of that step
         assert_close(got, ref, 2e-5, 1e-5, 'param after resumed step ' + k)
