@@ -108,7 +108,7 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
     from multimodal_outage_amd.trainer import FlatTrainer
     torch.manual_seed(42)
     m = Modified_UNET('gwnet', horizon, input_channels=cin, output_channels=cin, image_dimension=size).to(dev).train()
-    tr = FlatTrainer(m)
+    tr = FlatTrainer(m).attach()
     g = torch.Generator().manual_seed(2000 + int(os.environ.get('RANK', '0')))
     x = torch.randn(batch, 67, horizon, cin, size, size, generator=g).to(dev)
     y = torch.randn(batch, 67, horizon, cin, size, size, generator=g).to(dev)
@@ -235,6 +235,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get('MO_MAIN_HI'):        # experiment: the main chain on a high-priority stream
+        hi = torch.cuda.Stream(device=dev, priority=-1)
+        hi.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hi)
     for _ in range(args.warmup):
         step()
     sync()

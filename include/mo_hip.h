@@ -222,9 +222,10 @@ int mo_nchw_conv1x1_fwd(const float* in, long istride, int Ci, const float* sc, 
                         long ostride, void* stream);
 int mo_nchw_conv1x1_bwd_data(const float* dout, long dostride, int Co, const float* W, int Ci, long n_img,
                              int HW, float* din, long distride, void* stream);
+/* db (may be NULL): the bias gradient, sum of dout over images and pixels */
 int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride,
                                int Ci, const float* sc, const float* sh, int relu, int gsize, long n_img,
-                               int HW, float* dW, float* ws, void* stream);
+                               int HW, float* dW, float* db, float* ws, void* stream);
 /* Up.up (unet.py:71): ConvTranspose2d(Ci, Co, k=2, s=2) with bias; W (Ci, Co, 2, 2); H,Wd = input size */
 int mo_convt2x2_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                     int gsize, const float* W, const float* b, int Co, long n_img, int H, int Wd, float* out,

@@ -68,7 +68,7 @@ SIGNATURES = {
                                     i64, i32, i32, vp, vp, vp]),
     'mo_nchw_conv1x1_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, vp, i64, vp]),
     'mo_nchw_conv1x1_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, vp, i64, vp]),
-    'mo_nchw_conv1x1_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, vp, vp, vp]),
+    'mo_nchw_conv1x1_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, vp, vp, vp, vp]),
     'mo_convt2x2_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, i32, vp, i64, vp]),
     'mo_convt2x2_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, i32, vp, i64, vp]),
     'mo_convt2x2_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp]),

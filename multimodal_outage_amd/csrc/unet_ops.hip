@@ -7,6 +7,7 @@
 // ReLU) are applied on load and never materialised.
 #include "mo_gemm.hpp"
 #include "unet_direct.hpp"
+#include "unet_thin.hpp"
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
@@ -65,7 +66,7 @@ static void uplan(int M, int N, long P, int& nsplit, int& kchunk) {
 extern "C" long mo_unet_wgrad_ws_floats(int M, int N, long P) {
   int ns, kc; uplan(M, N, P, ns, kc);
   if (ns < UD_MAX_SLABS) ns = UD_MAX_SLABS;
-  return (long)ns * M * N + 64;
+  return (long)ns * ((long)M * N + M) + 64;           // (+ M: the thin 1x1 path keeps the bias sums in the same rows)
 }
 
 __global__ void uslab_reduce_kernel(const float* __restrict__ slab, long stride, int nz, float* __restrict__ out, long n) {
@@ -208,12 +209,30 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
 // ------------------------------------------------------------------------------------------------
 // 1x1 conv on NCHW (OutConv, unet.py:86-92)
 // ------------------------------------------------------------------------------------------------
+static bool ut_ok(const float* a, long as, const float* b, long bs, int Ca, int Cb, long n_img) {
+  return Ca <= 16 && Cb <= 16 && n_img <= 65535 && (((uintptr_t)a) & 15) == 0 && (((uintptr_t)b) & 15) == 0 &&
+         (as & 3) == 0 && (bs & 3) == 0;
+}
+template <bool TRANS>
+static int ut_launch(const UtArgs& a, hipStream_t st) {
+  int gx = mo_cdiv(a.HW, 1024); if (gx > 64) gx = 64;
+  dim3 grid(gx, (unsigned)a.n_img);
+  if (a.Co <= 4) hipLaunchKernelGGL((ut_conv1x1_kernel<4, TRANS>), grid, dim3(256), 0, st, a);
+  else if (a.Co <= 8) hipLaunchKernelGGL((ut_conv1x1_kernel<8, TRANS>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ut_conv1x1_kernel<16, TRANS>), grid, dim3(256), 0, st, a);
+  return mo_launch_status();
+}
 extern "C" int mo_nchw_conv1x1_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                                    int gsize, const float* W, const float* b, int Co, long n_img, int HW, float* out,
                                    long ostride, void* stream) {
   MO_CHECK_ARG(in && W && out && Ci > 0 && Co > 0 && n_img > 0 && HW > 0 && (HW % 4) == 0);
   const long P = n_img * HW;
   MO_CHECK_ARG(P < (1L << 31));
+  if (ut_ok(in, istride, out, ostride, Ci, Co, n_img)) {
+    UtArgs a; a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize;
+    a.W = W; a.b = b; a.out = out; a.os = ostride; a.Co = Co; a.n_img = n_img; a.HW = HW;
+    return ut_launch<false>(a, ST(stream));
+  }
   MoOperand A = uplain(W, Ci, Co, Ci);                                            // XROWS rows = co, cols = ci
   MoOperand B; uop(B, Ci, P); useg(B.seg[0], in, istride, sc, sh, relu);           // NCHW KROWS rows = ci, cols = p
   MoEpi E; uepi(E, out, ostride); E.bias = b;
@@ -224,17 +243,51 @@ extern "C" int mo_nchw_conv1x1_bwd_data(const float* dout, long dostride, int Co
                                         int HW, float* din, long distride, void* stream) {
   MO_CHECK_ARG(dout && W && din && Ci > 0 && Co > 0 && n_img > 0 && (HW % 4) == 0);
   const long P = n_img * HW;
+  if (ut_ok(dout, dostride, din, distride, Co, Ci, n_img)) {
+    UtArgs a; a.in = dout; a.is = dostride; a.Ci = Co; a.sc = nullptr; a.sh = nullptr; a.relu = 0; a.gsize = 1;
+    a.W = W; a.b = nullptr; a.out = din; a.os = distride; a.Co = Ci; a.n_img = n_img; a.HW = HW;
+    return ut_launch<true>(a, ST(stream));
+  }
   MoOperand A = uplain(W, Ci, Co, Ci);                                            // KROWS rows = k = co, cols = m = ci
   MoOperand B; uop(B, Co, P); useg(B.seg[0], dout, dostride, nullptr, nullptr, 0);  // NCHW KROWS rows = co
   MoEpi E; uepi(E, din, distride);
   MoGeom G = geom(1, HW, 1, Co, 0);
   return ulaunch_fwd<MO_KROWS, MO_EPI_NCHW, MO_SRC_PLAIN, MO_SRC_NCHW>(A, B, E, G, Ci, P, ST(stream));
 }
+extern "C" int mo_nchw_channel_sum(const float* x, long istride, int C, long n_img, int HW, float* out, float* ws,
+                                   void* stream);
 extern "C" int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride,
                                           int Ci, const float* sc, const float* sh, int relu, int gsize, long n_img,
-                                          int HW, float* dW, float* ws, void* stream) {
+                                          int HW, float* dW, float* db, float* ws, void* stream) {
   MO_CHECK_ARG(dout && in && dW && ws && Ci > 0 && Co > 0 && n_img > 0 && (HW % 4) == 0);
   const long P = n_img * HW;
+  const bool t44 = Ci <= 4 && Co <= 16, t88 = Ci <= 8 && Co <= 8, t416 = Ci <= 16 && Co <= 4;
+  if ((t44 || t88 || t416) && ut_ok(dout, dostride, in, istride, Co, Ci, n_img)) {
+    // thin layer: one streaming pass over dout and act(in), weight and bias sums together
+    int gx = mo_cdiv(HW, 1024); if (gx > 8) gx = 8;
+    long ipw = (n_img * gx + UD_MAX_SLABS - 1) / UD_MAX_SLABS; if (ipw < 1) ipw = 1;
+    const long gy = (n_img + ipw - 1) / ipw;
+    UtWgArgs a; a.dout = dout; a.dos = dostride; a.Co = Co; a.in = in; a.is = istride; a.Ci = Ci;
+    a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize; a.slab = ws; a.n_img = n_img; a.HW = HW;
+    a.img_per_wg = (int)ipw;
+    dim3 grid(gx, (unsigned)gy);
+    hipStream_t st = ST(stream);
+    if (t44) {
+      if (Co <= 4) hipLaunchKernelGGL((ut_wgrad1x1_kernel<4, 4>), grid, dim3(256), 0, st, a);
+      else if (Co <= 8) hipLaunchKernelGGL((ut_wgrad1x1_kernel<8, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((ut_wgrad1x1_kernel<16, 4>), grid, dim3(256), 0, st, a);
+    } else if (t88) hipLaunchKernelGGL((ut_wgrad1x1_kernel<8, 8>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((ut_wgrad1x1_kernel<4, 16>), grid, dim3(256), 0, st, a);
+    const long nw = (long)Co * Ci, nrow = nw + Co;
+    const int nz = (int)(gx * gy);
+    hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(nw, 32)), dim3(256), 0, st, ws, nrow, nz, dW, nw);
+    if (db) hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(Co, 32)), dim3(256), 0, st, ws + nw, nrow, nz, db, (long)Co);
+    return mo_launch_status();
+  }
+  if (db) {       // bias gradient of the general path: per-channel sum of dout (workspace: the head of ws, reused below)
+    int rc = mo_nchw_channel_sum(dout, dostride, Co, n_img, HW, db, ws, stream);
+    if (rc) return rc;
+  }
   // both operands are NCHW sources but with different channel counts / activations: run as
   // A = dout (rows = co), B = act(in) (rows = ci); the per-group affine index uses G.C0 = Ci, which only B reads
   MoOperand A; uop(A, Co, P); useg(A.seg[0], dout, dostride, nullptr, nullptr, 0);

@@ -197,6 +197,10 @@ def _use_ring(M, Ncols):
 
 
 _SKIP = os.environ.get('MO_SKIP', '')     # timing experiments only: drop a kernel class from the step
+# MO_OVL_DENSE=0: the dense products of the data path stay on the main stream (sparse branch first, then the dense
+# one); only the dA accumulations and the weight-gradient lane run beside the main chain
+OVL_DENSE = bool(int(os.environ.get('MO_OVL_DENSE', '0')))
+OVL_DA = bool(int(os.environ.get('MO_OVL_DA', '1')))      # 0: the dA accumulations stay on the main stream too
 
 
 def _adj_prod(A_bf, X_bf, Y, N, J, beta, Y_bf=None):
@@ -348,7 +352,8 @@ class GwnetFunction(torch.autograd.Function):
             if cfg.gcn:
                 # the dense (adaptive, MFMA-bound) branch runs on a side HIP stream beside the sparse
                 # (static CSR, HBM-bound) branch; both only read g and are joined in front of the mlp
-                side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap and not SERIAL) else None
+                side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap and not SERIAL
+                                             and OVL_DENSE) else None
                 dense_out = []
                 # bf16 mode keeps every diffusion intermediate (and, in backward, its gradient) as a bf16
                 # tensor only: the row-streaming kernels widen on load and narrow on store
@@ -570,7 +575,8 @@ class GwnetFunction(torch.autograd.Function):
                 k = 1
                 if cfg.gcn:
                     ka = 1 + 2 * len(statics)
-                    side = _side_stream(dev) if (cfg.adaptive and statics and cfg.overlap and not SERIAL) else None
+                    use_gs = bool(cfg.adaptive and statics and cfg.overlap and not SERIAL and OVL_DA)   # dA on its own stream
+                    side = _side_stream(dev) if (use_gs and OVL_DENSE) else None
                     if cfg.adaptive:
                         # dense branch, part 1 (does not touch dg): dx1 += adp.dx2 ; dA += x1.dx2^T ; dA += g.dx1^T
                         x1 = srcs[ka]
@@ -579,44 +585,33 @@ class GwnetFunction(torch.autograd.Function):
                         if side is not None:
                             side.wait_stream(main)
                         with torch.cuda.stream(side if side is not None else main):
-                            if ly['bf'] is not None:
+                            bf = ly['bf'] is not None
+                            if bf:
                                 g_bf, x1_bf = ly['bf']
-                                dx1_bf, dx2_bf = dx1, dx2          # already bf16 tensors
-                                _adj_prod(ctx.adp_bf, dx2_bf, None, N, J, 1, dx1_bf)
-                                # only dx1 is needed by the main chain; the two dA accumulations keep running
-                                # on the side stream beside the rest of this layer's backward
-                                if side is not None:
-                                    dx1_ready = torch.cuda.Event()
-                                    dx1_ready.record(side)
-                                    gs = _side_stream((dev, 'dagrad'))     # a third stream: keeps the dense
-                                    gs.wait_event(dx1_ready)               # stream free for the next layer
-                                    for t_ in (dx2_bf, dx1_bf):
-                                        t_.record_stream(gs)
-                                    with torch.cuda.stream(gs):
-                                        _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
-                                        _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
-                                else:
-                                    _adj_grad_bf(x1_bf, dx2_bf, dAdp, N, J, 1 if dAdp_started else 0)
-                                    _adj_grad_bf(g_bf, dx1_bf, dAdp, N, J, 1)
+                                _adj_prod(ctx.adp_bf, dx2, None, N, J, 1, dx1)        # dx1, dx2 are bf16 tensors
                             else:
-                                sst = L.stream()
-                                _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, sst)
-                                if side is not None:
-                                    dx1_ready = torch.cuda.Event()
-                                    dx1_ready.record(side)
-                                    gs = _side_stream((dev, 'dagrad'))
-                                    gs.wait_event(dx1_ready)
-                                    for t_ in (dx1, dx2):
-                                        t_.record_stream(gs)
-                                    with torch.cuda.stream(gs):
-                                        _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
-                                               1 if dAdp_started else 0, L.stream())
-                                        _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1,
-                                               L.stream())
+                                _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx2), L.ptr(dx1), J, 1, L.stream())
+
+                            def _dA(beta0):
+                                if bf:
+                                    _adj_grad_bf(x1_bf, dx2, dAdp, N, J, beta0)
+                                    _adj_grad_bf(g_bf, dx1, dAdp, N, J, 1)
                                 else:
-                                    _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp),
-                                           1 if dAdp_started else 0, sst)
-                                    _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, sst)
+                                    _dense('mo_adj_grad', N, J, L.ptr(x1), L.ptr(dx2), N, J, L.ptr(dAdp), beta0, L.stream())
+                                    _dense('mo_adj_grad', N, J, L.ptr(g), L.ptr(dx1), N, J, L.ptr(dAdp), 1, L.stream())
+                            # only dx1 is needed by the main chain; the two dA accumulations keep running on a third
+                            # stream beside the rest of this layer's backward
+                            if use_gs:
+                                dx1_ready = torch.cuda.Event()
+                                dx1_ready.record(torch.cuda.current_stream())
+                                gs = _side_stream((dev, 'dagrad'))
+                                gs.wait_event(dx1_ready)
+                                for t_ in (dx2, dx1):
+                                    t_.record_stream(gs)
+                                with torch.cuda.stream(gs):
+                                    _dA(1 if dAdp_started else 0)
+                            else:
+                                _dA(1 if dAdp_started else 0)
                             dAdp_started = True
                     for s in statics:
                         dx1s, dx2s = dsrcs[k], dsrcs[k + 1]
@@ -628,7 +623,7 @@ class GwnetFunction(torch.autograd.Function):
                             torch.cuda.current_stream().wait_event(dx1_ready)
                         # dense branch, part 2: dg += adp.dx1 (after the sparse accumulations into dg)
                         if ly['bf'] is not None:
-                            _adj_prod(ctx.adp_bf, dx1_bf, dg, N, J, 1)
+                            _adj_prod(ctx.adp_bf, dx1, dg, N, J, 1)
                         else:
                             _dense('mo_adj_gemm', N, J, L.ptr(ctx.adpT), N, L.ptr(dx1), L.ptr(dg), J, 1, st)
                 beta = 1

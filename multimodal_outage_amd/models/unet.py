@@ -160,8 +160,12 @@ class Modified_UNET(nn.Module):
         assert NC == self.n_counties and H == self.horizon and S == self.image_dimension
         n = B * NC * H
         named = dict(self.named_parameters())
+        # optional {parameter name: preallocated gradient tensor} of a flat-buffer trainer (FlatTrainer.attach): the
+        # engine then writes the UNet-side gradients in place instead of handing new tensors to autograd.  The
+        # Graph-WaveNet inside is called once per batch element (unet.py:221), so its gradients must accumulate
+        # through autograd and are not registered here.
         state = dict(gsize=H, training=self.training, bufs=self._bufs(),
-                     fc_dropout=self.encoder.dropout1.p)
+                     fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None))
         enc_names = self._names(('contraction', 'encoder'))
         dec_names = self._names(('decoder', 'expansion'))
         st_e = dict(state, names=enc_names)

@@ -110,6 +110,20 @@ class FlatTrainer:
         """{name-without-prefix: grad view} for an engine that writes gradients in place."""
         return {k[len(prefix):]: v for k, v in self.grad_views.items() if k.startswith(prefix)}
 
+    def attach(self):
+        """Let the engines write gradients straight into the flat gradient buffer (no autograd accumulation kernels):
+        Graph-WaveNet as the top-level module, and the UNet-side Functions of Modified_UNET.  One forward/backward
+        per step (an engine overwrites its gradients, it does not accumulate across several backward passes)."""
+        from .models.graph_wavenet import gwnet
+        from .models.unet import Modified_UNET
+        m = self.module
+        if isinstance(m, gwnet):
+            m._mo_grad_out = self.grad_out()
+            m._mo_grad_ready = self.ready_callback()
+        elif isinstance(m, Modified_UNET):
+            m._mo_grad_out = {k: v for k, v in self.grad_views.items() if not k.startswith('st_gnn.')}
+        return self
+
     def zero_grad(self):
         self.flat_g.zero_()
 

@@ -36,6 +36,25 @@ def _empty(*shape, dev):
     return torch.empty(shape, device=dev, dtype=torch.float32)
 
 
+class Grads(dict):
+    """Gradient destinations of one backward pass: the trainer's flat-buffer view when one is registered for the key
+    (state['grad_out'], written in place and NOT handed to autograd), else a new tensor."""
+
+    def __init__(self, gout, dev):
+        super().__init__()
+        self.gout, self.dev = gout or {}, dev
+
+    def buf(self, key, shape):
+        t = self.gout.get(key)
+        if t is None:
+            t = torch.empty(tuple(shape), device=self.dev, dtype=torch.float32)
+        self[key] = t
+        return t
+
+    def result(self, names):
+        return tuple(None if (k in self.gout and self.gout[k] is not None) else self.get(k) for k in names)
+
+
 def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev):
     v0 = views[0]
     H, W = v0.H, v0.W
@@ -95,24 +114,22 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
 
     def act_bwd(y, aff, bnkey, da_t, dp_t):
         dy = _empty(n, Co, H, W, dev=dev)
-        dg = _empty(Co, dev=dev)
-        db = _empty(Co, dev=dev)
+        dg = grads.buf(bnkey + '.weight', (Co,))
+        db = grads.buf(bnkey + '.bias', (Co,))
         ws = torch.empty(lib.mo_unet_act_bwd_ws_floats(n, Co), device=dev, dtype=torch.float32)
         da_t, das = _dastride(da_t)
         L.call('mo_unet_act_bwd', L.ptr(y), Co * HW, Co, n, H, W, gs, L.ptr(p[bnkey + '.weight']), L.ptr(aff[2]),
                L.ptr(aff[3]), L.ptr(aff[0]), L.ptr(aff[1]), da_t.data_ptr() if da_t is not None else None, das,
                L.ptr(dp_t), (Co * HW) // 4, L.ptr(dy), Co * HW, L.ptr(dg), L.ptr(db), L.ptr(ws), st)
-        grads[bnkey + '.weight'], grads[bnkey + '.bias'] = dg, db
         return dy
 
     def wgrad(dy, views, wkey):
         Ci = sum(v.C for v in views)
-        dW = _empty(Co, Ci, 3, 3, dev=dev)
+        dW = grads.buf(wkey, (Co, Ci, 3, 3))
         ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * HW), device=dev, dtype=torch.float32)
         a1 = views[1].args() if len(views) > 1 else _NOVIEW
         L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * HW, Co, *views[0].args(), *a1, gs, n, H, W, L.ptr(dW),
                L.ptr(ws), st)
-        grads[wkey] = dW
 
     def dgrad(dy, Wt):
         Ci = Wt.shape[1]
@@ -172,11 +189,10 @@ def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True):
     def lin_bwd(dout, inp, wkey, bkey, need_in):
         W = p[wkey]
         Co, Ci = W.shape
-        dW = torch.empty_like(W)
-        db = _empty(Co, dev=dev)
+        dW = grads.buf(wkey, (Co, Ci))
+        db = grads.buf(bkey, (Co,))
         ws = torch.empty(lib.mo_wgrad_ws_floats(Co, Ci, P), device=dev, dtype=torch.float32)
         L.call('mo_conv1x1_bwd_weight', L.ptr(dout), Co, P, L.ptr(inp), Ci, 0, 0, 0, 0, L.ptr(dW), L.ptr(db), L.ptr(ws), st)
-        grads[wkey], grads[bkey] = dW, db
         if not need_in:
             return None
         din = _empty(P, Ci, dev=dev)
@@ -254,7 +270,7 @@ class UnetEncodeFn(torch.autograd.Function):
         state, p, saved, n = ctx.state, ctx.p, ctx.saved, ctx.n
         gs = state['gsize']
         dev = dfeat.device
-        grads = {}
+        grads = Grads(state.get('grad_out'), dev)
         outs = ctx.saved_tensors
         fc_sv = dict(ctx.fc_sv, h2=outs[0])
         saved = [dict(sv, y2=outs[1 + k]) if k < 4 else sv for k, sv in enumerate(saved)]
@@ -265,7 +281,7 @@ class UnetEncodeFn(torch.autograd.Function):
         for k in (3, 2, 1, 0):
             need = (k > 0) or ctx.x_needs_grad
             dp = double_conv_bwd(p, saved[k], n, gs, grads, dev, da=dfm[k], dp=dp, need_input_grad=need)
-        return (None, dp) + tuple(grads.get(k) for k in state['names'])
+        return (None, dp) + grads.result(state['names'])
 
 
 class UnetDecodeFn(torch.autograd.Function):
@@ -311,19 +327,17 @@ class UnetDecodeFn(torch.autograd.Function):
         gs = state['gsize']
         dev = dout.device
         st = L.stream()
-        grads = {}
+        grads = Grads(state.get('grad_out'), dev)
         dout = dout.contiguous()
         Wo = p['expansion.outc.conv.weight']
         Cout, C4 = Wo.shape[0], Wo.shape[1]
         HW = v.H * v.W
-        dWo = torch.empty_like(Wo)
-        ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), device=dev, dtype=torch.float32)
+        dWo = grads.buf('expansion.outc.conv.weight', Wo.shape)
+        dbo = grads.buf('expansion.outc.conv.bias', (Cout,))
+        ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), n * Cout * 2), device=dev,
+                         dtype=torch.float32)
         L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Cout * HW, Cout, L.ptr(v.t), v.istride, C4, L.ptr(v.sc),
-               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(ws), st)
-        dbo = _empty(Cout, dev=dev)
-        ws2 = _empty(n * Cout * 2, dev=dev)
-        L.call('mo_nchw_channel_sum', L.ptr(dout), Cout * HW, Cout, n, HW, L.ptr(dbo), L.ptr(ws2), st)
-        grads['expansion.outc.conv.weight'], grads['expansion.outc.conv.bias'] = dWo, dbo
+               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), st)
         da = _empty(n, C4, v.H, v.W, dev=dev)
         L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW, st)
         dfm = [None] * 4
@@ -336,15 +350,14 @@ class UnetDecodeFn(torch.autograd.Function):
             du = dcat[:, C0:]
             du_stride = dcat.stride(0)
             Wt = p[f'expansion.up{k}.up.weight']
-            dWt = torch.empty_like(Wt)
+            dWt = grads.buf(f'expansion.up{k}.up.weight', Wt.shape)
             wsu = torch.empty(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), device=dev, dtype=torch.float32)
             L.call('mo_convt2x2_bwd_weight', du.data_ptr(), du_stride, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
                    L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(wsu), st)
-            dbt = _empty(C0, dev=dev)
+            dbt = grads.buf(f'expansion.up{k}.up.bias', (C0,))
             wsb = _empty(n * C0 * 2, dev=dev)
             L.call('mo_nchw_channel_sum', du.data_ptr(), du_stride, C0, n, 4 * H * H, L.ptr(dbt), L.ptr(wsb), st)
-            grads[f'expansion.up{k}.up.weight'], grads[f'expansion.up{k}.up.bias'] = dWt, dbt
             da = _empty(n, ci, H, H, dev=dev)
             L.call('mo_convt2x2_bwd_data', du.data_ptr(), du_stride, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
         dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads)
-        return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + tuple(grads.get(k) for k in state['names'])
+        return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(state['names'])

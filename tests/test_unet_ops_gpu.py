@@ -148,7 +148,8 @@ def test_convt2x2_fwd_bwd(L, n, gs, Ci, Co, H, W, act):
     close(db, b.grad, what='convT db')
 
 
-@pytest.mark.parametrize('n,gs,Ci,Co,HW', [(4, 2, 4, 1, 256), (2, 1, 4, 3, 64)])
+@pytest.mark.parametrize('n,gs,Ci,Co,HW', [(4, 2, 4, 1, 256), (2, 1, 4, 3, 64), (6, 2, 4, 13, 64 * 64), (4, 2, 8, 8, 1028),
+                                          (2, 2, 13, 4, 2048), (2, 1, 24, 20, 256), (3, 3, 4, 16, 5000)])
 def test_outconv_fwd_bwd(L, n, gs, Ci, Co, HW):
     lib = L.load()
     G = n // gs
@@ -172,10 +173,12 @@ def test_outconv_fwd_bwd(L, n, gs, Ci, Co, HW):
            L.stream())
     close(din, a.grad.reshape(n, Ci, HW), what='outc bwd data')
     dW = torch.empty(Co, Ci, device='cuda')
-    ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci, n * HW), device='cuda')
+    db = torch.empty(Co, device='cuda')
+    ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Co, Ci, n * HW), n * Co * 2), device='cuda')
     L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dd), Co * HW, Co, L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, n,
-           HW, L.ptr(dW), L.ptr(ws), L.stream())
+           HW, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
     close(dW, Wt.grad.reshape(Co, Ci), what='outc dW')
+    close(db, b.grad, what='outc db')
 
 
 def test_dropout_mask(L):

@@ -27,7 +27,7 @@ def main():
     from multimodal_outage_amd.trainer import FlatTrainer
     torch.manual_seed(42)
     m = Modified_UNET('gwnet', a.horizon, input_channels=a.cin, output_channels=a.cin, image_dimension=a.size).cuda().train()
-    tr = FlatTrainer(m)
+    tr = FlatTrainer(m).attach()
     B, H, S = a.batch, a.horizon, a.size
     x = torch.randn(B, 67, H, a.cin, S, S, device='cuda')
     y = torch.randn(B, 67, H, a.cin, S, S, device='cuda')
