@@ -261,6 +261,9 @@ int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint32_t thresh,
 /* ReLU backward on a materialised activation y: out = (y > 0) ? dy : 0 (fc layers, unet.py:142-144) */
 int mo_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream);
 
+/* A/B switches of the UNet kernels for measurements: "no_mfma_wgrad" (1: the VALU / split-K 3x3 weight gradients) */
+int mo_unet_set_option(const char* name, int value);
+
 /* ---- data-parallel exchange step: gradient all-reduce over RCCL / xGMI ---------------------------------
  * Replaces Lightning's implicit DDP(NCCL) gradient all-reduce (lit.py:204; the reference has no explicit distributed
  * code).  One communicator per process (= per GPU).  Rank 0 calls mo_allreduce_unique_id and hands the 128 bytes to

@@ -229,3 +229,154 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 convs on the fp32 matrix pipe (exact fp32: v_mfma_f32_16x16x4_f32 is bit for bit a
+// k-ordered fmaf chain).  The reduction over pixels is what made the VALU form above expensive: every thread kept
+// 72 partial sums and 4x2-channel blocks re-read dy and the halo per block.  Here the sum over pixels IS the MFMA's k:
+//   D[m = (ci,tap)][j = co] += A[m][k] * B[k][j],   k = 4 neighbouring pixels of one row,
+//   A[m][k] = act(in)[ci][y + ky - 1][x0 + k + kx - 1]   (a gather from the LDS halo tile: one ds_read_b32 per lane),
+//   B[k][j] = dy[co][y][x0 + k]                          (LDS, planes padded so that the 16 channels hit 16 banks),
+// so a wave accumulates all Co x 16 input channels x 9 taps in 4*MB*NB registers over every pixel it visits and the
+// workgroup's partial result is folded once, at the end of its image range.  One workgroup = one 8 x 64 tile
+// position x a range of images x one chunk of 16 input channels; slab rows as for ud_wgrad3x3_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef float uw_f32x4 __attribute__((ext_vector_type(4)));
+#define UW_TH 8
+#define UW_TW 64
+#define UW_LDT 72                     // halo row: col 3 = x0-1, cols 4..67 = interior, col 68 = x0+64
+#define UW_PS (10 * UW_LDT + 8)       // halo plane stride (+8: planes 24 banks apart, rows 8)
+#define UW_CIC 16                     // input channels per workgroup
+#define UW_DPS (UW_TH * UW_TW + 4)    // dy plane stride (+4: channel j of the B fragment lands on bank 4j + k)
+
+// dynamic LDS: max(cmax*UW_PS + Co*UW_DPS, 4*NB*MB*256) floats, cmax = min(Ci, UW_CIC) -- sized by the layer, so that
+// the thin layers (20 KB) put 4..8 workgroups on a CU and hide their own staging latency
+static inline size_t uw_lds_bytes(int Ci, int Co, int NB, int MB) {
+  const int cmax = Ci < UW_CIC ? Ci : UW_CIC;
+  size_t a = (size_t)cmax * UW_PS + (size_t)Co * UW_DPS, b = (size_t)4 * NB * MB * 256;
+  return (a > b ? a : b) * sizeof(float);
+}
+template <int NB, int MB>             // Co <= 16*NB, chunk channels * 9 <= 16*MB
+__global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int cmax = min(a.C0 + a.C1, UW_CIC);
+  float* xs = lds;
+  float* dys = lds + cmax * UW_PS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = a.Wd / UW_TW;
+  const int x0 = (blockIdx.x % tiles_x) * UW_TW, y0 = (blockIdx.x / tiles_x) * UW_TH;
+  const long img0 = (long)blockIdx.y * a.img_per_wg;
+  const long img1 = min(img0 + a.img_per_wg, a.n_img);
+  const int Ci = a.C0 + a.C1;
+  const int ci0 = blockIdx.z * UW_CIC;
+  const int cic = min(UW_CIC, Ci - ci0);
+  UdConvArgs ca;
+  ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
+  ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
+  ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize;
+
+  // per-lane fragment geometry
+  int abase[MB]; float amask[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = mb * 16 + (lane & 15);
+    const bool ok = m < cic * 9;
+    const int mm = ok ? m : 0;
+    const int ci = mm / 9, tap = mm - 9 * ci, ky = tap / 3, kx = tap - 3 * ky;
+    abase[mb] = ci * UW_PS + ky * UW_LDT + kx + 3 + (lane >> 4);
+    amask[mb] = ok ? 1.f : 0.f;
+  }
+  int bbase[NB]; float bmask[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = nb * 16 + (lane & 15);
+    bbase[nb] = (co < a.Co ? co : 0) * UW_DPS + (lane >> 4);
+    bmask[nb] = co < a.Co ? 1.f : 0.f;
+  }
+
+  uw_f32x4 acc[NB][MB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (uw_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int i = tid; i < cmax * UW_PS; i += 256) xs[i] = 0.f;            // (channels >= cic are masked, keep them finite)
+
+  for (long img = img0; img < img1; ++img) {
+    const long grp = img / a.gsize;
+    __syncthreads();                                                   // previous tile fully consumed
+    // activated halo tile: interior quads as aligned float4, the two halo columns as scalars
+    for (int idx = tid; idx < cic * (UW_TH + 2) * (UW_TW / 4); idx += 256) {
+      const int c = idx / ((UW_TH + 2) * (UW_TW / 4)), r = idx - c * ((UW_TH + 2) * (UW_TW / 4));
+      const int yy = r / (UW_TW / 4), q = r - yy * (UW_TW / 4);
+      const int y = y0 + yy - 1, x = x0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)y < (unsigned)a.H) {
+        const int cg = ci0 + c;
+        const bool first = cg < a.C0;
+        const int cc = first ? cg : cg - a.C0;
+        const float* base = first ? a.in0 : a.in1;
+        const long is = first ? a.is0 : a.is1;
+        v = *reinterpret_cast<const float4*>(&base[img * is + ((long)cc * a.H + y) * a.Wd + x]);
+        const float* sc = first ? a.sc0 : a.sc1;
+        if (sc) {
+          const float* sh = first ? a.sh0 : a.sh1;
+          const long gi = grp * (first ? a.C0 : a.C1) + cc;
+          const float s_ = sc[gi], t_ = sh[gi];
+          v.x = v.x * s_ + t_; v.y = v.y * s_ + t_; v.z = v.z * s_ + t_; v.w = v.w * s_ + t_;
+        }
+        if (first ? a.relu0 : a.relu1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      *reinterpret_cast<float4*>(&xs[c * UW_PS + yy * UW_LDT + 4 + 4 * q]) = v;
+    }
+    for (int idx = tid; idx < cic * (UW_TH + 2) * 2; idx += 256) {
+      const int c = idx / ((UW_TH + 2) * 2), r = idx - c * ((UW_TH + 2) * 2);
+      const int yy = r >> 1, side = r & 1;
+      xs[c * UW_PS + yy * UW_LDT + (side ? UW_TW + 4 : 3)] =
+          ud_act(ca, img, grp, ci0 + c, y0 + yy - 1, side ? x0 + UW_TW : x0 - 1);
+    }
+    for (int idx = tid; idx < a.Co * UW_TH * (UW_TW / 4); idx += 256) {
+      const int co = idx / (UW_TH * (UW_TW / 4)), r = idx - co * (UW_TH * (UW_TW / 4));
+      const int yy = r / (UW_TW / 4), q = r - yy * (UW_TW / 4);
+      const float4 d = *reinterpret_cast<const float4*>(&a.dy[img * a.dys + ((long)co * a.H + y0 + yy) * a.Wd + x0 + 4 * q]);
+      *reinterpret_cast<float4*>(&dys[co * UW_DPS + yy * UW_TW + 4 * q]) = d;
+    }
+    __syncthreads();
+    // this wave's two rows, 16 pixel quads each
+#pragma unroll 2
+    for (int it = 0; it < 32; ++it) {
+      const int yy = wave * 2 + (it >> 4), q = it & 15;
+      const int aoff = yy * UW_LDT + 4 * q, boff = yy * UW_TW + 4 * q;
+      float bv[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bv[nb] = dys[bbase[nb] + boff] * bmask[nb];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float av = xs[abase[mb] + aoff] * amask[mb];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[nb][mb], 0, 0, 0);
+      }
+    }
+  }
+  // fold the four waves (fixed order) and write this workgroup's slab row
+  __syncthreads();
+  float* red = lds;                                                    // [4][NB*MB*256]
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * NB * MB + nb * MB + mb) * 256 + r * 64 + lane] = acc[nb][mb][r];
+  __syncthreads();
+  const long z = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  float* row = a.slab + z * ((long)a.Co * Ci * 9);
+  for (int e = tid; e < NB * MB * 256; e += 256) {
+    const int blk = e >> 8, r = (e >> 6) & 3, l = e & 63;
+    const int nb = blk / MB, mb = blk - nb * MB;
+    const int co = nb * 16 + (l & 15), m = mb * 16 + (l >> 4) * 4 + r;
+    if (co < a.Co && m < cic * 9) {
+      const float s = (red[e] + red[NB * MB * 256 + e]) + (red[2 * NB * MB * 256 + e] + red[3 * NB * MB * 256 + e]);
+      row[((long)co * Ci + ci0) * 9 + m] = s;          // (ci0 + m/9)*9 + m%9 == ci0*9 + m
+    }
+  }
+}

@@ -5,12 +5,20 @@
 // (M = channels, N = pixels, K = Ci*9) on the fp32 MFMA engine of mo_gemm.hpp with an im2col /
 // NCHW / transposed-conv gather loader; "activated views" (raw conv output + folded group-BN affine +
 // ReLU) are applied on load and never materialised.
+#include <string.h>
+
 #include "mo_gemm.hpp"
 #include "unet_direct.hpp"
 #include "unet_thin.hpp"
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
+static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 = previous VALU / split-K weight gradients
+extern "C" int mo_unet_set_option(const char* name, int value) {
+  if (!name) return MO_EINVAL;
+  if (!strcmp(name, "no_mfma_wgrad")) { mo_opt_no_mfma_wgrad = value; return MO_OK; }
+  return MO_EINVAL;
+}
 
 static void useg(MoSeg& s, const float* ptr, long istride, const float* sc, const float* sh, int relu) {
   s.ptr = ptr; s.scale = sc; s.shift = sh; s.ld = (int)istride;
@@ -63,9 +71,12 @@ static void uplan(int M, int N, long P, int& nsplit, int& kchunk) {
   nsplit = (int)((P + kchunk - 1) / kchunk); if (nsplit < 1) nsplit = 1;
 }
 #define UD_MAX_SLABS 512     // direct 3x3 weight gradient: slab rows (tile positions x image ranges)
+#define UW_THIN_ROW 4608     // layers with Co*Ci*9 up to this many weights (32 x 16 x 9) ...
+#define UW_THIN_SLABS 2048   // ... may use this many slab rows: enough workgroups to hide their staging latency
 extern "C" long mo_unet_wgrad_ws_floats(int M, int N, long P) {
   int ns, kc; uplan(M, N, P, ns, kc);
-  if (ns < UD_MAX_SLABS) ns = UD_MAX_SLABS;
+  const int floor_rows = ((long)M * N <= UW_THIN_ROW) ? UW_THIN_SLABS : UD_MAX_SLABS;
+  if (ns < floor_rows) ns = floor_rows;
   return (long)ns * ((long)M * N + M) + 64;           // (+ M: the thin 1x1 path keeps the bias sums in the same rows)
 }
 
@@ -173,6 +184,36 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
   MO_CHECK_ARG(P < (1L << 31));
   const int Ci = C0 + C1;
   const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
+  if (Co <= 32 && (Wd % UW_TW) == 0 && (H % UW_TH) == 0 && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0 &&
+      mo_cdiv(Ci, UW_CIC) < 65536 && !mo_opt_no_mfma_wgrad) {
+    // 3x3 weight gradient on the fp32 matrix pipe (unet_direct.hpp): the sum over pixels is the MFMA's k
+    const long tiles = (long)(Wd / UW_TW) * (H / UW_TH);
+    const long max_rows = ((long)Co * Ci * 9 <= UW_THIN_ROW) ? UW_THIN_SLABS : UD_MAX_SLABS;
+    long ipw = (n_img * tiles + max_rows - 1) / max_rows;                 // images per workgroup
+    if (ipw < 1) ipw = 1;
+    const long nchunk = (n_img + ipw - 1) / ipw;
+    if (tiles * nchunk <= max_rows && tiles < (1L << 31) && nchunk < 65536) {
+      UdWgradArgs a;
+      a.dy = dy; a.dys = dystride;
+      a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
+      a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
+      a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+      a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UW_CIC);
+      dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)a.n_cichunk);
+      hipStream_t st = ST(stream);
+      const int cmax = Ci < UW_CIC ? Ci : UW_CIC;
+#define UW_LAUNCH1(NB, MB) do { static bool attr_set = false; const size_t lb = uw_lds_bytes(Ci, Co, NB, MB); \
+        if (!attr_set) { hipFuncSetAttribute((const void*)uw_wgrad_mfma_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((uw_wgrad_mfma_kernel<NB, MB>), grid, dim3(256), lb, st, a); } while (0)
+#define UW_LAUNCH(NB) do { if (cmax * 9 <= 48) UW_LAUNCH1(NB, 3); else if (cmax * 9 <= 80) UW_LAUNCH1(NB, 5); else UW_LAUNCH1(NB, 9); } while (0)
+      if (Co <= 16) UW_LAUNCH(1); else UW_LAUNCH(2);
+#undef UW_LAUNCH
+#undef UW_LAUNCH1
+      const long n = (long)Co * Ci * 9;
+      hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(256), 0, st, ws, n, (int)(tiles * nchunk), dW, n);
+      return mo_launch_status();
+    }
+  }
   if (Co <= 32 && (long)Co * Ci <= 128 && H >= 32 && Wd >= 32 && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0) {
     // thin layers (Co*Ci <= 128, measured crossover: beyond it the 4x2-channel blocking re-reads dy / the halo too
     // often and the split-K implicit GEMM wins): direct weight gradient on LDS spatial tiles (unet_direct.hpp)
@@ -484,6 +525,41 @@ __device__ __forceinline__ float unet_dz(const float* __restrict__ yp, int H, in
   }
   return d;
 }
+// dz of the 4 pixels (yy, 4q..4q+3) of one channel plane: 16-byte loads; with max-pool routing the partner row of the
+// 2x2 windows is read as well (the first maximum in scan order takes the pooled gradient, as F.max_pool2d does)
+__device__ __forceinline__ void unet_dz4(const float* __restrict__ yp, int W, int yy, int q, float s, float t,
+                                         const float* __restrict__ da_p, const float* __restrict__ dp_p, float4& yv,
+                                         float (&dz)[4]) {
+  yv = *reinterpret_cast<const float4*>(yp + (long)yy * W + 4 * q);
+  const float a[4] = {yv.x * s + t, yv.y * s + t, yv.z * s + t, yv.w * s + t};
+  float d[4] = {0.f, 0.f, 0.f, 0.f};
+  if (da_p) {
+    const float4 v = *reinterpret_cast<const float4*>(da_p + (long)yy * W + 4 * q);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  if (dp_p) {
+    const float4 ov = *reinterpret_cast<const float4*>(yp + (long)(yy ^ 1) * W + 4 * q);
+    const float o[4] = {ov.x * s + t, ov.y * s + t, ov.z * s + t, ov.w * s + t};
+    const float2 g = *reinterpret_cast<const float2*>(dp_p + (long)(yy >> 1) * (W >> 1) + 2 * q);
+    const bool top = (yy & 1) == 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      // window values in scan order: top-left, top-right, bottom-left, bottom-right
+      const float v0 = top ? a[2 * w] : o[2 * w], v1 = top ? a[2 * w + 1] : o[2 * w + 1];
+      const float v2 = top ? o[2 * w] : a[2 * w], v3 = top ? o[2 * w + 1] : a[2 * w + 1];
+      int am = 0; float mx = v0;
+      if (v1 > mx) { mx = v1; am = 1; }
+      if (v2 > mx) { mx = v2; am = 2; }
+      if (v3 > mx) { mx = v3; am = 3; }
+      const int me0 = top ? 0 : 2;
+      const float gw = w ? g.y : g.x;
+      if (am == me0) d[2 * w] += gw;
+      if (am == me0 + 1) d[2 * w + 1] += gw;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dz[i] = (a[i] > 0.f) ? d[i] : 0.f;
+}
 __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                             const float* __restrict__ sc, const float* __restrict__ sh,
@@ -496,12 +572,15 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
   const float* yp = y + img * istride + (long)c * H * W;
   const float* dap = da ? da + img * dastride + (long)c * H * W : nullptr;
   const float* dpp = dp ? dp + img * dpstride + (long)c * (H / 2) * (W / 2) : nullptr;
+  const int Q = W >> 2;
   float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
-    const int yy = i / W, x = i - yy * W;
-    const float dz = unet_dz(yp, H, W, yy, x, s, t, dap, dpp);
-    const float xh = (yp[i] - mu) * rs;
-    s1 += dz; s2 += dz * xh;
+  for (int i = threadIdx.x; i < H * Q; i += blockDim.x) {
+    const int yy = i / Q, q = i - yy * Q;
+    float4 yv; float dz[4];
+    unet_dz4(yp, W, yy, q, s, t, dap, dpp, yv, dz);
+    const float xh[4] = {(yv.x - mu) * rs, (yv.y - mu) * rs, (yv.z - mu) * rs, (yv.w - mu) * rs};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1 += dz[k]; s2 += dz[k] * xh[k]; }
   }
   sm[0][threadIdx.x] = s1; sm[1][threadIdx.x] = s2;
   __syncthreads();
@@ -539,10 +618,11 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
                                           const float* __restrict__ rstd, const float* __restrict__ sc,
                                           const float* __restrict__ sh, const float* __restrict__ da, long dastride,
                                           const float* __restrict__ dp, long dpstride, const float* __restrict__ k12,
-                                          float* __restrict__ dy, long dystride, long total) {
+                                          float* __restrict__ dy, long dystride, long total4) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int x = (int)(i % W); long r = i / W;
+  if (i >= total4) return;
+  const int Q = W >> 2;
+  const int q = (int)(i % Q); long r = i / Q;
   const int yy = (int)(r % H); r /= H;
   const int c = (int)(r % C); const long img = r / C;
   const long g = img / gsize;
@@ -550,10 +630,15 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   const float* yp = y + img * istride + (long)c * H * W;
   const float* dap = da ? da + img * dastride + (long)c * H * W : nullptr;
   const float* dpp = dp ? dp + img * dpstride + (long)c * (H / 2) * (W / 2) : nullptr;
-  const float dz = unet_dz(yp, H, W, yy, x, s, t, dap, dpp);
-  const float xh = (yp[(long)yy * W + x] - mu) * rs;
-  dy[img * dystride + ((long)c * H + yy) * W + x] =
-      gamma[c] * rs * (dz - k12[(g * C + c) * 2] - xh * k12[(g * C + c) * 2 + 1]);
+  float4 yv; float dz[4];
+  unet_dz4(yp, W, yy, q, s, t, dap, dpp, yv, dz);
+  const float k1 = k12[(g * C + c) * 2], k2 = k12[(g * C + c) * 2 + 1], gr = gamma[c] * rs;
+  float4 o;
+  o.x = gr * (dz[0] - k1 - (yv.x - mu) * rs * k2);
+  o.y = gr * (dz[1] - k1 - (yv.y - mu) * rs * k2);
+  o.z = gr * (dz[2] - k1 - (yv.z - mu) * rs * k2);
+  o.w = gr * (dz[3] - k1 - (yv.w - mu) * rs * k2);
+  *reinterpret_cast<float4*>(dy + img * dystride + ((long)c * H + yy) * W + 4 * q) = o;
 }
 extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * 4 + 64; }
 extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
@@ -563,6 +648,9 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   MO_CHECK_ARG(y && gamma && mean && rstd && sc && sh && dy && dgamma && dbeta && ws && (da || dp));
   MO_CHECK_ARG(C > 0 && n_img > 0 && n_img <= 65535 && gsize > 0 && (n_img % gsize) == 0);
   MO_CHECK_ARG(!dp || ((H % 2) == 0 && (Wd % 2) == 0));
+  MO_CHECK_ARG((Wd % 4) == 0 && (((uintptr_t)y) & 15) == 0 && (istride & 3) == 0 && (((uintptr_t)dy) & 15) == 0 &&
+               (dystride & 3) == 0 && (!da || ((((uintptr_t)da) & 15) == 0 && (dastride & 3) == 0)) &&
+               (!dp || ((((uintptr_t)dp) & 7) == 0 && (dpstride & 1) == 0)));
   hipStream_t st = ST(stream);
   float* part = ws;
   float* k12 = ws + n_img * C * 2;
@@ -572,9 +660,9 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   const long G = n_img / gsize;
   hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, k12);
   hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
-  const long total = n_img * C * HW;
-  hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
-                     gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total);
+  const long total4 = n_img * C * (HW / 4);
+  hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total4, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
+                     gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4);
   return mo_launch_status();
 }
 

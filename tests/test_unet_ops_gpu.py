@@ -22,7 +22,11 @@ def act_view(y, sc, sh, gsize):
                                                 (2, 1, 64, 0, 64, 8, 8), (3, 3, 4, 4, 4, 32, 32), (2, 2, 32, 32, 32, 16, 16),
                                                 # direct-convolution path (thin layers at >= 32x32): ragged tiles, odd channel counts
                                                 (2, 1, 13, 0, 4, 32, 64), (2, 2, 5, 3, 13, 48, 80), (1, 1, 20, 12, 32, 32, 36),
-                                                (2, 1, 4, 0, 8, 128, 128)])
+                                                (2, 1, 4, 0, 8, 128, 128),
+                                                # MFMA weight-gradient path (W % 64 == 0, H % 8 == 0): 3 / 5 / 9 m-blocks, two views,
+                                                # two input-channel chunks (ragged second chunk), 32 output channels, many images per workgroup
+                                                (4, 2, 13, 0, 4, 64, 64), (3, 1, 8, 0, 8, 16, 128), (2, 2, 4, 4, 4, 24, 64), (2, 1, 16, 16, 16, 64, 64),
+                                                (2, 2, 12, 8, 32, 32, 64), (40, 2, 4, 0, 4, 64, 128), (2, 1, 5, 0, 16, 8, 64)])
 def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W):
     lib = L.load()
     G = n // gs
