@@ -207,7 +207,11 @@ int mo_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
 int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, const float* sh0, int relu0,
                    const float* in1, int C1, long istride1, const float* sc1, const float* sh1, int relu1,
                    int gsize, const float* W, int Co, long n_img, int H, int Wd, float* out, long ostride,
+                   float* stats /* optional [n_img][tiles][Co][2] per-tile (sum, sumsq) of out, tiles =
+                   mo_conv3x3_stats_tiles(): the BatchNorm statistics come out of the conv's epilogue; NULL: none */,
                    void* stream);
+/* per-image statistics rows mo_conv3x3_fwd writes for this shape (0: none -- run mo_nchw_stats on the output) */
+int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
 /* Wf[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]; the data gradient is mo_conv3x3_fwd(dy, Wf). */
 int mo_conv3x3_flip_weights(const float* W, int Co, int Ci, float* Wf, void* stream);
 long mo_unet_wgrad_ws_floats(int M, int N, long P);
@@ -239,7 +243,8 @@ int mo_convt2x2_bwd_weight(const float* dout, long dostride, int Co, const float
 int mo_nchw_stats(const float* y, long istride, int C, long n_img, int HW, float* stats, void* stream);
 /* per-group finalize: scale/shift/mean/rstd [G][C]; running stats receive G sequential momentum updates
  * in group order (= the reference's county-then-batch order of nn.BatchNorm2d calls) */
-int mo_group_bn_finalize(const float* stats, long n_img, int C, int gsize, int HW, const float* gamma,
+int mo_group_bn_finalize(const float* stats /* [n_img][ntile][C][2] */, long n_img, int C, int gsize, int HW,
+                         int ntile /* statistics rows per image: 1 for mo_nchw_stats */, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum,
                          float eps, int training, float* scale, float* shift, float* mean, float* rstd,
                          void* stream);

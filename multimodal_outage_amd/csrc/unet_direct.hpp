@@ -15,6 +15,7 @@ struct UdConvArgs {
   const float* W;          // (Co, C0+C1, 3, 3)
   float* out; long os;
   int Co, H, Wd, gsize;
+  float* stats;            // optional [img][tile][Co][2]: per-tile (sum, sum of squares) of the raw outputs
 };
 
 // activated value of channel c (of the concat) at (y, x) of image img; zero outside the image
@@ -123,12 +124,33 @@ __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
     }
   }
   const int y = y0 + ty, x = x0 + tx4;
-  if (y < a.H && x < a.Wd) {                                     // Wd % 4 == 0: a quad is all in or all out
+  const bool valid = y < a.H && x < a.Wd;                        // Wd % 4 == 0: a quad is all in or all out
+  if (valid) {
 #pragma unroll
     for (int co = 0; co < CO; ++co)
       if (co < a.Co)
         *reinterpret_cast<float4*>(&a.out[img * a.os + ((long)co * a.H + y) * a.Wd + x]) =
             make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+  }
+  if (a.stats) {
+    // BatchNorm statistics of this tile straight from the accumulators (fixed order: 4 pixels, wave shuffles, the four
+    // waves through LDS) -- the separate pass over the conv output is gone
+    __shared__ float red[4][2 * CO];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float s1 = valid ? (acc[co][0] + acc[co][1]) + (acc[co][2] + acc[co][3]) : 0.f;
+      float s2 = valid ? (acc[co][0] * acc[co][0] + acc[co][1] * acc[co][1]) + (acc[co][2] * acc[co][2] + acc[co][3] * acc[co][3]) : 0.f;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (lane == 0) { red[wave][2 * co] = s1; red[wave][2 * co + 1] = s2; }
+    }
+    __syncthreads();
+    if (tid < 2 * CO && (tid >> 1) < a.Co) {
+      const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x, ntile = (long)gridDim.x * gridDim.y;
+      a.stats[((img * ntile + tile) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
   }
 }
 
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
   UdConvArgs ca;
   ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
   ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
-  ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize;
+  ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize; ca.stats = nullptr;
 
   float acc[UD_WC][UD_WI][9];
 #pragma unroll
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
   UdConvArgs ca;
   ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
   ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
-  ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize;
+  ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize; ca.stats = nullptr;
 
   // per-lane fragment geometry
   int abase[MB]; float amask[MB];

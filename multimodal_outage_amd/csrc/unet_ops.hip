@@ -80,18 +80,28 @@ extern "C" long mo_unet_wgrad_ws_floats(int M, int N, long P) {
   return (long)ns * ((long)M * N + M) + 64;           // (+ M: the thin 1x1 path keeps the bias sums in the same rows)
 }
 
-__global__ void uslab_reduce_kernel(const float* __restrict__ slab, long stride, int nz, float* __restrict__ out, long n) {
-  __shared__ float sm[8][33];
+// out[i] = sum_z slab[z][i] in a fixed order: 32 columns x 32 row groups per workgroup, four independent partial sums
+// per thread (up to 2048 rows of the thin layers' weight gradients would otherwise be one dependent add chain)
+__global__ __launch_bounds__(1024) void uslab_reduce_kernel(const float* __restrict__ slab, long stride, int nz,
+                                                            float* __restrict__ out, long n) {
+  __shared__ float sm[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const long i = (long)blockIdx.x * 32 + tx;
-  float s = 0.f;
-  if (i < n) for (int z = ty; z < nz; z += 8) s += slab[(long)z * stride + i];
-  sm[ty][tx] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int z = ty;
+    for (; z + 96 < nz; z += 128) {
+      s0 += slab[(long)z * stride + i]; s1 += slab[(long)(z + 32) * stride + i];
+      s2 += slab[(long)(z + 64) * stride + i]; s3 += slab[(long)(z + 96) * stride + i];
+    }
+    for (; z < nz; z += 32) s0 += slab[(long)z * stride + i];
+  }
+  sm[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ty == 0 && i < n) {
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t += sm[q][tx];
+    for (int q = 0; q < 32; ++q) t += sm[q][tx];
     out[i] = t;
   }
 }
@@ -105,7 +115,7 @@ static int uwgrad(const MoOperand& A, const MoOperand& B, const MoGeom& G, int M
   int rc = ulaunch<64, 64, 32, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE, ASRC, BSRC>(A, B, E, G, M, N, nsplit, st);
   if (rc) return rc;
   long n = (long)M * N;
-  hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(256), 0, st, ws, n, nsplit, dW, n);
+  hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(1024), 0, st, ws, n, nsplit, dW, n);
   return mo_launch_status();
 }
 
@@ -129,19 +139,31 @@ static MoOperand im2col_operand(const float* in0, int C0, long is0, const float*
   return o;
 }
 
+static bool ud_conv_direct(const float* in0, long istride0, const float* in1, int C1, long istride1, int Co, long n_img,
+                           int H, int Wd, const float* out, long ostride) {
+  const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
+  return Co <= 32 && H >= 32 && Wd >= 32 && n_img < 65536 && in_al && (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0;
+}
+// Number of per-tile statistics rows per image that mo_conv3x3_fwd writes for this shape when given a `stats` buffer
+// ([n_img][tiles][Co][2] floats); 0 = this shape runs on the implicit-GEMM path, which produces none (use mo_nchw_stats).
+extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd) {
+  if (!(Co <= 32 && H >= 32 && Wd >= 32 && n_img < 65536 && (Wd % 4) == 0)) return 0;
+  const bool wide = Wd >= 64;
+  return mo_cdiv(Wd, wide ? 64 : 32) * mo_cdiv(H, wide ? 16 : 32);
+}
 extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, const float* sh0, int relu0,
                               const float* in1, int C1, long istride1, const float* sc1, const float* sh1, int relu1,
                               int gsize, const float* W, int Co, long n_img, int H, int Wd, float* out, long ostride,
-                              void* stream) {
+                              float* stats, void* stream) {
   MO_CHECK_ARG(in0 && W && out && C0 > 0 && C1 >= 0 && Co > 0 && n_img > 0 && H > 0 && Wd > 0 && (Wd % 4) == 0);
   MO_CHECK_ARG(C1 == 0 || in1);
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31) && istride0 < (1L << 31) && ostride < (1L << 31));
   const int Ci = C0 + C1;
   // thin layers at >= 32x32 pixels: direct convolution on LDS spatial tiles (unet_direct.hpp)
-  const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
-  if (Co <= 32 && H >= 32 && Wd >= 32 && n_img < 65536 && in_al && (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0) {
+  if (ud_conv_direct(in0, istride0, in1, C1, istride1, Co, n_img, H, Wd, out, ostride)) {
     UdConvArgs a;
+    a.stats = stats;
     a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
     a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
     a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
@@ -154,6 +176,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
 #undef UD_LAUNCH
     return mo_launch_status();
   }
+  MO_CHECK_ARG(!stats);                          // (mo_conv3x3_stats_tiles() == 0 for every shape that gets here ...
   MoOperand A = uplain(W, Ci * 9, Co, Ci * 9);   // XROWS: rows = m = co, cols = k = (ci,tap)
   MoOperand B = im2col_operand(in0, C0, istride0, sc0, sh0, relu0, in1, C1, istride1, sc1, sh1, relu1, P);
   MoEpi E; uepi(E, out, ostride);
@@ -210,7 +233,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
 #undef UW_LAUNCH
 #undef UW_LAUNCH1
       const long n = (long)Co * Ci * 9;
-      hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(256), 0, st, ws, n, (int)(tiles * nchunk), dW, n);
+      hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(1024), 0, st, ws, n, (int)(tiles * nchunk), dW, n);
       return mo_launch_status();
     }
   }
@@ -235,7 +258,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       if (wide) hipLaunchKernelGGL((ud_wgrad3x3_kernel<16, 64>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((ud_wgrad3x3_kernel<32, 32>), grid, dim3(256), 0, st, a);
       const long n = (long)Co * Ci * 9;
-      hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(256), 0, st, ws, n, (int)(tiles * nchunk), dW, n);
+      hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(1024), 0, st, ws, n, (int)(tiles * nchunk), dW, n);
       return mo_launch_status();
     }
   }
@@ -321,8 +344,8 @@ extern "C" int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int 
     else hipLaunchKernelGGL((ut_wgrad1x1_kernel<4, 16>), grid, dim3(256), 0, st, a);
     const long nw = (long)Co * Ci, nrow = nw + Co;
     const int nz = (int)(gx * gy);
-    hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(nw, 32)), dim3(256), 0, st, ws, nrow, nz, dW, nw);
-    if (db) hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(Co, 32)), dim3(256), 0, st, ws + nw, nrow, nz, db, (long)Co);
+    hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(nw, 32)), dim3(1024), 0, st, ws, nrow, nz, dW, nw);
+    if (db) hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(Co, 32)), dim3(1024), 0, st, ws + nw, nrow, nz, db, (long)Co);
     return mo_launch_status();
   }
   if (db) {       // bias gradient of the general path: per-channel sum of dout (workspace: the head of ws, reused below)
@@ -406,7 +429,7 @@ extern "C" int mo_nchw_stats(const float* y, long istride, int C, long n_img, in
 // group BatchNorm finalize: groups of gsize consecutive images; running stats updated group by group in
 // order (the reference's per-county, per-batch-element sequence of nn.BatchNorm2d calls)
 // stage A: one thread per (group, channel) -> mean / rstd / folded affine
-__global__ void group_bn_stats_kernel(const float* __restrict__ stats, long G, int C, int gsize, int HW,
+__global__ void group_bn_stats_kernel(const float* __restrict__ stats, long G, int C, int gsize, int HW, int ntile,
                                       const float* gamma, const float* beta, const float* running_mean,
                                       const float* running_var, float eps, int training, float* scale, float* shift,
                                       float* mean_out, float* rstd_out) {
@@ -417,8 +440,8 @@ __global__ void group_bn_stats_kernel(const float* __restrict__ stats, long G, i
   if (training) {
     const double M = (double)gsize * HW;
     double s1 = 0.0, s2 = 0.0;
-    for (int j = 0; j < gsize; ++j) {
-      const float* st = stats + ((g * gsize + j) * C + c) * 2;
+    for (long j = 0; j < (long)gsize * ntile; ++j) {          // rows (image, tile) of the group are consecutive
+      const float* st = stats + ((g * gsize * ntile + j) * C + c) * 2;
       s1 += st[0]; s2 += st[1];
     }
     double m = s1 / M, v = s2 / M - m * m;
@@ -451,15 +474,16 @@ __global__ void group_bn_running_kernel(const float* __restrict__ mean_g, const 
   }
   running_mean[c] = rm; running_var[c] = rv;
 }
-extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int gsize, int HW, const float* gamma,
+extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int gsize, int HW, int ntile,
+                                    const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float momentum,
                                     float eps, int training, float* scale, float* shift, float* mean, float* rstd,
                                     void* stream) {
   MO_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && mean && rstd);
-  MO_CHECK_ARG(C > 0 && gsize > 0 && n_img > 0 && (n_img % gsize) == 0 && (!training || stats));
+  MO_CHECK_ARG(C > 0 && gsize > 0 && n_img > 0 && (n_img % gsize) == 0 && (!training || stats) && ntile >= 1);
   const long G = n_img / gsize;
   hipLaunchKernelGGL(group_bn_stats_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, ST(stream), stats, G, C, gsize, HW,
-                     gamma, beta, running_mean, running_var, eps, training, scale, shift, mean, rstd);
+                     ntile, gamma, beta, running_mean, running_var, eps, training, scale, shift, mean, rstd);
   if (training)
     hipLaunchKernelGGL(group_bn_running_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, ST(stream), mean, rstd, G, C, gsize,
                        HW, momentum, eps, running_mean, running_var);

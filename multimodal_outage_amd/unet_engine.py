@@ -61,15 +61,18 @@ def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev):
     st = L.stream()
     y = _empty(n, Co, H, W, dev=dev)
     a1 = views[1].args() if len(views) > 1 else _NOVIEW
-    L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, st)
+    # train mode: the BatchNorm statistics come out of the conv's own epilogue where the direct kernels run
+    # (per-tile partial sums), else from one pass over the output
+    ntile = L.load().mo_conv3x3_stats_tiles(Co, n, H, W) if training else 0
+    stats = _empty(n, ntile, Co, 2, dev=dev) if ntile else None
+    L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, L.ptr(stats), st)
     G = n // gs
     aff = _empty(4, G, Co, dev=dev)            # scale, shift, mean, rstd
-    stats = None
-    if training:
+    if training and not ntile:
         stats = _empty(n, Co, 2, dev=dev)
         L.call('mo_nchw_stats', L.ptr(y), Co * H * W, Co, n, H * W, L.ptr(stats), st)
     rm, rv, nbt = bufs[bnkey]
-    L.call('mo_group_bn_finalize', L.ptr(stats), n, Co, gs, H * W, L.ptr(p[bnkey + '.weight']),
+    L.call('mo_group_bn_finalize', L.ptr(stats), n, Co, gs, H * W, max(ntile, 1), L.ptr(p[bnkey + '.weight']),
            L.ptr(p[bnkey + '.bias']), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, 1 if training else 0,
            L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(aff[2]), L.ptr(aff[3]), st)
     if training:
@@ -136,7 +139,7 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
         Wf = _flip(Wt, dev)
         dx = _empty(n, Ci, H, W, dev=dev)
         L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wf), Ci, n, H, W,
-               L.ptr(dx), Ci * HW, st)
+               L.ptr(dx), Ci * HW, None, st)
         return dx
 
     dy2 = act_bwd(sv['y2'], sv['aff2'], pre + '.double_conv.4', da, dp)

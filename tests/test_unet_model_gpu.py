@@ -48,7 +48,9 @@ def test_modified_unet_vs_golden(name, B, channels, size, seed):
         assert (g is None or float(g.abs().max()) == 0.0) == (k in none), k
     worst = check_grads_vs_f64({k: g for k, g in grads.items() if g is not None}, G)
     print(name, 'worst gradient error vs float64 reference (relative to tensor max):', worst)
-    check_grads(grads, G, atol=2e-6, rtol=1e-2, scale_rel=1e-2)      # and loosely against the fp32 golden
+    # and loosely against the fp32 golden: two fp32 evaluations of sums with heavy cancellation, each ~1 % of the
+    # tensor's scale away from the float64 truth (the bound above), so 2 % of scale between them
+    check_grads(grads, G, atol=2e-6, rtol=1e-2, scale_rel=2e-2)
     sd = m.state_dict()
     for k in G.files:
         if k.startswith('buf/'):

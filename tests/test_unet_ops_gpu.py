@@ -44,8 +44,17 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W):
     x1d = dev(x1.detach()) if C1 else None
     args_in = (L.ptr(x0d), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1,
                L.ptr(x1d), C1, C1 * H * W, None, None, 0)
-    L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(dev(Wt.detach())), Co, n, H, W, L.ptr(out), Co * H * W, L.stream())
+    ntile = lib.mo_conv3x3_stats_tiles(Co, n, H, W)
+    stats = torch.full((n, max(ntile, 1), Co, 2), float('nan'), device='cuda')
+    L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(dev(Wt.detach())), Co, n, H, W, L.ptr(out), Co * H * W,
+           L.ptr(stats) if ntile else None, L.stream())
     close(out, ref, what='conv fwd')
+    if ntile:
+        # BatchNorm statistics from the conv epilogue: per-tile (sum, sum of squares) rows add up to the per-image sums
+        st = stats.cpu().double().sum(1)
+        rd = ref.detach().double()
+        close(st[..., 0], rd.sum((2, 3)), tol=1e-5, what='epilogue sum')
+        close(st[..., 1], (rd * rd).sum((2, 3)), tol=1e-5, what='epilogue sumsq')
     dy = rand(6, tuple(ref.shape))
     ref.backward(dy)
     # data gradient = conv of dy with the flipped/transposed weights -> gradient w.r.t. the *activated* cat
@@ -54,7 +63,7 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W):
     L.call('mo_conv3x3_flip_weights', L.ptr(dev(Wt.detach())), Co, Ci, L.ptr(Wf), L.stream())
     dcat = torch.empty(n, Ci, H, W, device='cuda')
     L.call('mo_conv3x3_fwd', L.ptr(dev(dy)), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wf), Ci,
-           n, H, W, L.ptr(dcat), Ci * H * W, L.stream())
+           n, H, W, L.ptr(dcat), Ci * H * W, None, L.stream())
     dcat_ref = F.conv_transpose2d(dy, Wt.detach(), padding=1)
     close(dcat, dcat_ref, what='conv bwd data')
     if C1:
@@ -86,7 +95,7 @@ def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da):
     rmd, rvd = dev(rm0.clone()), dev(rv0.clone())
     aff = torch.empty(4, G, C, device='cuda')
     gd, bd = dev(gamma.detach()), dev(beta.detach())
-    L.call('mo_group_bn_finalize', L.ptr(stats), n, C, gs, H * W, L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), 0.1, 1e-5, 1,
+    L.call('mo_group_bn_finalize', L.ptr(stats), n, C, gs, H * W, 1, L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), 0.1, 1e-5, 1,
            L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(aff[2]), L.ptr(aff[3]), L.stream())
     close(rmd, rm, 1e-5, 'running_mean (sequential group updates)')
     close(rvd, rv, 1e-5, 'running_var')
