@@ -261,6 +261,10 @@ int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int 
 /* out[c] = sum over images and pixels (bias gradients); ws: n_img*C*2 floats */
 int mo_nchw_channel_sum(const float* x, long istride, int C, long n_img, int HW, float* out, float* ws,
                         void* stream);
+/* nn.MaxPool2d(2) backward on a plain NCHW tensor x (Down.forward called on its own, unet.py:55-65): dx gets dp at the
+ * first maximum of every 2x2 window and 0 elsewhere.  Forward = mo_unet_act with sc = sh = NULL, pool = 1. */
+int mo_maxpool2_bwd(const float* x, long istride, int C, long n_img, int H, int Wd, const float* dp, long dpstride,
+                    float* dx, long dxstride, void* stream);
 /* nn.Dropout (unet.py:135,159) with the counter-based mask; the same call is its own backward */
 int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint32_t thresh, float scale, void* stream);
 /* ReLU backward on a materialised activation y: out = (y > 0) ? dy : 0 (fc layers, unet.py:142-144) */

@@ -81,6 +81,7 @@ SIGNATURES = {
     'mo_unet_act_bwd': (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                               vp, vp, vp, vp]),
     'mo_nchw_channel_sum': (i32, [vp, i64, i32, i64, i32, vp, vp, vp]),
+    'mo_maxpool2_bwd': (i32, [vp, i64, i32, i64, i32, i32, vp, i64, vp, i64, vp]),
     'mo_dropout': (i32, [vp, vp, i64, u32, u32, f32, vp]),
     'mo_relu_bwd': (i32, [vp, vp, vp, i64, vp]),
     # ---- RCCL exchange step / host CSR builder

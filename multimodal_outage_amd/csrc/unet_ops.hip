@@ -526,6 +526,35 @@ extern "C" int mo_unet_act(const float* y, long istride, int C, long n_img, int 
   return mo_launch_status();
 }
 
+// nn.MaxPool2d(2) backward on a plain tensor (Down.forward on its own, unet.py:55-65; inside the batched engine the pool
+// is folded into the activation backward below): dx = dp routed to the first maximum of each 2x2 window, else 0
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, long istride, int C, int H, int W,
+                                    const float* __restrict__ dp, long dpstride, float* __restrict__ dx, long dxstride,
+                                    long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Wo = W / 2, Ho = H / 2;
+  const int xo = (int)(i % Wo); long r = i / Wo;
+  const int yo = (int)(r % Ho); r /= Ho;
+  const int c = (int)(r % C); const long img = r / C;
+  const float* q = x + img * istride + ((long)c * H + 2 * yo) * W + 2 * xo;
+  const float v[4] = {q[0], q[1], q[W], q[W + 1]};
+  int am = 0; float mx = v[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (v[k] > mx) { mx = v[k]; am = k; }
+  const float g = dp[img * dpstride + ((long)c * Ho + yo) * Wo + xo];
+  float* o = dx + img * dxstride + ((long)c * H + 2 * yo) * W + 2 * xo;
+  o[0] = am == 0 ? g : 0.f; o[1] = am == 1 ? g : 0.f; o[W] = am == 2 ? g : 0.f; o[W + 1] = am == 3 ? g : 0.f;
+}
+extern "C" int mo_maxpool2_bwd(const float* x, long istride, int C, long n_img, int H, int Wd, const float* dp,
+                               long dpstride, float* dx, long dxstride, void* stream) {
+  MO_CHECK_ARG(x && dp && dx && C > 0 && n_img > 0 && H > 0 && Wd > 0 && (H % 2) == 0 && (Wd % 2) == 0);
+  const long total = n_img * C * (H / 2) * (Wd / 2);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(mo_cdiv(total, 256)), dim3(256), 0, ST(stream), x, istride, C, H, Wd, dp,
+                     dpstride, dx, dxstride, total);
+  return mo_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward through ReLU + group BatchNorm (+ max-pool routing)
 //   a  = relu(y*sc+sh)                     (recomputed)

@@ -24,7 +24,8 @@ compression_factor = 4
 
 
 class DoubleConv(nn.Module):
-    """unet.py:40-53 (parameter container; computed inside the batched engine)."""
+    """unet.py:40-53.  Inside Modified_UNET the block is computed by the batched engine; called on its own it runs the
+    same HIP ops on the tensor it is given (one BatchNorm group = the whole batch, as nn.BatchNorm2d)."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -37,6 +38,10 @@ class DoubleConv(nn.Module):
             nn.ReLU(inplace=True)
         )
 
+    def forward(self, x):
+        from ..unet_blocks import double_conv_forward
+        return double_conv_forward(self, x)
+
 
 class Down(nn.Module):
     """unet.py:55-65."""
@@ -44,6 +49,10 @@ class Down(nn.Module):
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
+
+    def forward(self, x):
+        from ..unet_blocks import double_conv_forward
+        return double_conv_forward(self.maxpool_conv[1], x, pool=True)
 
 
 class Up(nn.Module):
@@ -54,6 +63,10 @@ class Up(nn.Module):
         self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
         self.conv = DoubleConv(in_channels, out_channels)
 
+    def forward(self, x1, x2):
+        from ..unet_blocks import up_forward
+        return up_forward(self, x1, x2)
+
 
 class OutConv(nn.Module):
     """unet.py:86-92."""
@@ -61,6 +74,10 @@ class OutConv(nn.Module):
     def __init__(self, in_channels, out_channels):
         super(OutConv, self).__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def forward(self, x):
+        from ..unet_blocks import outconv_forward
+        return outconv_forward(self, x)
 
 
 class Contraction(nn.Module):
@@ -76,6 +93,11 @@ class Contraction(nn.Module):
         self.down4 = (Down(32, 64))
         self.feature_maps = [[] for _ in range(4)]
 
+    def forward(self, input):
+        """(n_counties, H, Cin, S, S) -> (n_counties, H, 64*(S/16)^2); self.feature_maps <- the four skip maps."""
+        from ..unet_blocks import contraction_forward
+        return contraction_forward(self, input)
+
 
 class Encoder(nn.Module):
     """unet.py:128-149."""
@@ -88,6 +110,10 @@ class Encoder(nn.Module):
         self.fc1 = nn.Linear(self.first_layer_size, int(self.first_layer_size / self.compression_factor))
         self.dropout1 = nn.Dropout(p=0.3)
         self.fc2 = nn.Linear(int(self.first_layer_size / self.compression_factor), feature_vector_size)
+
+    def forward(self, input):
+        from ..unet_blocks import fc_forward
+        return fc_forward(self, input)
 
 
 class Decoder(nn.Module):
@@ -103,6 +129,11 @@ class Decoder(nn.Module):
         self.dropout1 = nn.Dropout(p=0.3)
         self.fc2 = nn.Linear(int(feature_vector_size * self.compression_factor), self.output_layer_size)
 
+    def forward(self, input):
+        from ..unet_blocks import fc_forward
+        out = fc_forward(self, input)
+        return out.view(input.shape[0], self.horizon, 64, self.downsized_image_dimension, self.downsized_image_dimension)
+
 
 class Expansion(nn.Module):
     """unet.py:175-199."""
@@ -114,6 +145,10 @@ class Expansion(nn.Module):
         self.up3 = (Up(16, 8))
         self.up4 = (Up(8, 4))
         self.outc = (OutConv(4, output_channels))
+
+    def forward(self, input, feature_maps):
+        from ..unet_blocks import expansion_forward
+        return expansion_forward(self, input, feature_maps)
 
 
 class Modified_UNET(nn.Module):

@@ -134,7 +134,7 @@ def test_unet_blocks():
 
     p = vals('double_conv', dc_shapes('', 3, 8))
     run('double_conv', p, lambda p, x: unet_ref.double_conv(_Pre(p, 'm.'), 'm', x, True),
-        [rand(seed + 10, (2, 3, 12, 10))])
+        [rand(seed + 10, (2, 3, 12, 12))])
     p = vals('down', dc_shapes('maxpool_conv.1.', 4, 8))
     run('down', p, lambda p, x: unet_ref.down(_Pre(p, 'm.'), 'm', x, True),
         [rand(seed + 10, (3, 4, 16, 16))])
@@ -142,10 +142,40 @@ def test_unet_blocks():
     sh.update({'up.weight': (16, 8, 2, 2), 'up.bias': (8,)})
     p = vals('up', sh)
     run('up', p, lambda p, a, b: unet_ref.up(_Pre(p, 'm.'), 'm', a, b, True),
-        [rand(seed + 10, (2, 16, 5, 6)), rand(seed + 11, (2, 8, 11, 13))])
+        [rand(seed + 10, (2, 16, 6, 8)), rand(seed + 11, (2, 8, 12, 16))])
     p = vals('outc', {'conv.weight': (2, 4, 1, 1), 'conv.bias': (2,)})
     run('outc', p, lambda p, x: F.conv2d(x, p['conv.weight'], p['conv.bias']),
-        [rand(seed + 10, (2, 4, 9, 7))])
+        [rand(seed + 10, (2, 4, 8, 8))])
+    # composite blocks (unet.py:95-199): Contraction -> Encoder -> Decoder -> Expansion, 3 counties x 2 days of 32x32
+    NC, H, S = 3, 2, 32
+    p = {}
+    for nm, sd in zip(('contraction', 'encoder', 'decoder', 'expansion'), G['composite/seeds']):
+        keys = [str(k) for k in G[nm + '/keys']]
+        shp = {k: tuple(G[f'{nm}/grad/{k}'].shape) if f'{nm}/grad/{k}' in G.files else
+               (tuple(G[f'{nm}/buf/{k}'].shape)) for k in keys}
+        for k, v in P.as_param_dict(P.seeded_values(shp, int(sd))).items():
+            p[f'{nm}.{k}'] = v
+    x = rand(seed + 30, (NC, H, 2, S, S)).requires_grad_(True)
+    feat, fms = unet_ref.contraction(p, x, H, True)
+    assert_close(feat, G['composite/feat'], 1e-5, 1e-5, 'contraction')
+    for k in range(4):
+        assert_close(fms[k], G[f'composite/fm{k}'], 1e-5, 1e-5, f'fm{k}')
+    z = unet_ref.fc_block(p, 'encoder', feat, 0.0, True)
+    assert_close(z, G['composite/z'], 1e-5, 1e-5, 'encoder')
+    e = unet_ref.fc_block(p, 'decoder', z, 0.0, True).view(NC, H, 64, 2, 2)
+    assert_close(e, G['composite/e'], 1e-5, 1e-5, 'decoder')
+    y = unet_ref.expansion(p, e, fms, True)
+    assert_close(y, G['composite/y'], 1e-5, 1e-5, 'expansion')
+    loss = F.mse_loss(y, rand(seed + 31, tuple(y.shape)))
+    assert abs(loss.item() - float(G['composite/loss'])) < 1e-6
+    loss.backward()
+    assert_close(x.grad, G['composite/dx'], 1e-7, 1e-3, 'composite dx')
+    for k, v in p.items():
+        nm, kk = k.split('.', 1)
+        if v.requires_grad:
+            assert_close(v.grad, G[f'{nm}/grad/{kk}'], 1e-6, 2e-3, k)
+        elif f'{nm}/buf/{kk}' in G.files:
+            assert_close(v, G[f'{nm}/buf/{kk}'], 1e-6, 1e-5, k)
 
 
 class _Pre:

@@ -99,10 +99,12 @@ def unet_blocks_case(seed=300):
     d = {}
     # DoubleConv / Down / Up / OutConv at tiny shapes (unet.py:40-92)
     for nm, ctor, shapes in (
-            ('double_conv', lambda: ns['DoubleConv'](3, 8), [(2, 3, 12, 10)]),
+            # image widths are multiples of 4 and Up's skip map is exactly twice the upsampled size (what even image
+            # sizes give): the shapes the HIP path serves
+            ('double_conv', lambda: ns['DoubleConv'](3, 8), [(2, 3, 12, 12)]),
             ('down', lambda: ns['Down'](4, 8), [(3, 4, 16, 16)]),
-            ('up', lambda: ns['Up'](16, 8), [(2, 16, 5, 6), (2, 8, 11, 13)]),
-            ('outc', lambda: ns['OutConv'](4, 2), [(2, 4, 9, 7)])):
+            ('up', lambda: ns['Up'](16, 8), [(2, 16, 6, 8), (2, 8, 12, 16)]),
+            ('outc', lambda: ns['OutConv'](4, 2), [(2, 4, 8, 8)])):
         torch.manual_seed(0)
         m = ctor()
         vals = P.seeded_values({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
@@ -122,6 +124,40 @@ def unet_blocks_case(seed=300):
         for k, v in buffers(m).items():
             d[f'{nm}/{k}'] = v
         d[nm + '/keys'] = np.array([k for k in m.state_dict().keys()])
+    # the composite blocks (unet.py:95-199) at 3 counties x 2 days of 32x32 tiles: the module globals n_counties /
+    # image_dimension the reference reads are set by the loader
+    NC, H, S = 3, 2, 32
+    ns3 = R.load_unet(ns_g['gwnet'], n_counties=NC, image_dimension=S)
+    torch.manual_seed(0)
+    con, enc, dec, exp = ns3['Contraction'](2, H), ns3['Encoder'](), ns3['Decoder'](H), ns3['Expansion'](2)
+    for j, (nm, m) in enumerate((('contraction', con), ('encoder', enc), ('decoder', dec), ('expansion', exp))):
+        P.load_into(m, P.seeded_values({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed + 40 + j))
+        m.train()
+        if hasattr(m, 'dropout1'):
+            m.dropout1.p = 0.0
+        d[nm + '/keys'] = np.array(list(m.state_dict().keys()))
+    d['composite/seeds'] = np.array([seed + 40 + j for j in range(4)])
+    x = rand(seed + 30, (NC, H, 2, S, S)).requires_grad_(True)
+    feat = con(x)                                              # (3, 2, 256)
+    fms = con.feature_maps
+    z = enc(feat)                                              # (3, 2, 256)
+    e = dec(z)                                                 # (3, 2, 64, 2, 2)
+    y = exp(e, fms)                                            # (3, 2, 2, 32, 32)
+    loss = F.mse_loss(y, rand(seed + 31, tuple(y.shape)))
+    loss.backward()
+    d['composite/feat'] = feat.detach().numpy()
+    d['composite/z'] = z.detach().numpy()
+    d['composite/e'] = e.detach().numpy()
+    d['composite/y'] = y.detach().numpy()
+    d['composite/loss'] = np.float64(loss.item())
+    d['composite/dx'] = x.grad.numpy()
+    for k, fm in enumerate(fms):
+        d[f'composite/fm{k}'] = fm.detach().numpy()
+    for nm, m in (('contraction', con), ('encoder', enc), ('decoder', dec), ('expansion', exp)):
+        for k, prm in m.named_parameters():
+            d[f'{nm}/grad/{k}'] = prm.grad.numpy()
+        for k, v in buffers(m).items():
+            d[f'{nm}/{k}'] = v
     np.savez_compressed(os.path.join(OUT, 'unet_blocks.npz'), **d)
     print('unet_blocks done')
 
