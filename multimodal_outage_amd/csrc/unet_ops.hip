@@ -617,8 +617,11 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                             const float* __restrict__ sc, const float* __restrict__ sh,
                                             const float* __restrict__ da, long dastride, const float* __restrict__ dp,
-                                            long dpstride, float* __restrict__ part) {
-  __shared__ float sm[2][256];
+                                            long dpstride, double* __restrict__ part) {
+  // The two sums feed mean subtractions whose error is multiplied by sum(x) in the weight gradients downstream (x >= 0
+  // after ReLU, so that factor does not cancel): thread-private partial sums in fp32 over at most 64 quads, everything
+  // above that in double (torch's CPU BatchNorm backward accumulates in double too).
+  __shared__ double sm[2][256];
   const int c = blockIdx.x; const long img = blockIdx.y;
   const long g = img / gsize;
   const float s = sc[g * C + c], t = sh[g * C + c], mu = mean[g * C + c], rs = rstd[g * C + c];
@@ -626,14 +629,14 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
   const float* dap = da ? da + img * dastride + (long)c * H * W : nullptr;
   const float* dpp = dp ? dp + img * dpstride + (long)c * (H / 2) * (W / 2) : nullptr;
   const int Q = W >> 2;
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;
   for (int i = threadIdx.x; i < H * Q; i += blockDim.x) {
     const int yy = i / Q, q = i - yy * Q;
     float4 yv; float dz[4];
     unet_dz4(yp, W, yy, q, s, t, dap, dpp, yv, dz);
     const float xh[4] = {(yv.x - mu) * rs, (yv.y - mu) * rs, (yv.z - mu) * rs, (yv.w - mu) * rs};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { s1 += dz[k]; s2 += dz[k] * xh[k]; }
+    s1 += (double)((dz[0] + dz[1]) + (dz[2] + dz[3]));
+    s2 += (double)dz[0] * xh[0] + (double)dz[1] * xh[1] + (double)dz[2] * xh[2] + (double)dz[3] * xh[3];
   }
   sm[0][threadIdx.x] = s1; sm[1][threadIdx.x] = s2;
   __syncthreads();
@@ -643,7 +646,7 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
   }
   if (threadIdx.x == 0) { part[(img * C + c) * 2] = sm[0][0]; part[(img * C + c) * 2 + 1] = sm[1][0]; }
 }
-__global__ void unet_act_bwd_final_kernel(const float* __restrict__ part, long G, int C, int gsize, int HW,
+__global__ void unet_act_bwd_final_kernel(const double* __restrict__ part, long G, int C, int gsize, int HW,
                                           float* __restrict__ k12 /* [G][C][2] */) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G * C) return;
@@ -651,7 +654,7 @@ __global__ void unet_act_bwd_final_kernel(const float* __restrict__ part, long G
   const double M = (double)gsize * HW;
   double s1 = 0.0, s2 = 0.0;
   for (int j = 0; j < gsize; ++j) {
-    const float* p = part + ((g * gsize + j) * C + c) * 2;
+    const double* p = part + ((g * gsize + j) * C + c) * 2;
     s1 += p[0]; s2 += p[1];
   }
   k12[i * 2] = (float)(s1 / M);
@@ -693,7 +696,7 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   o.w = gr * (dz[3] - k1 - (yv.w - mu) * rs * k2);
   *reinterpret_cast<float4*>(dy + img * dystride + ((long)c * H + yy) * W + 4 * q) = o;
 }
-extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * 4 + 64; }
+extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * 6 + 64; }   // double partials + k12
 extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
                                const float* gamma, const float* mean, const float* rstd, const float* sc,
                                const float* sh, const float* da, long dastride, const float* dp, long dpstride,
@@ -705,8 +708,9 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
                (dystride & 3) == 0 && (!da || ((((uintptr_t)da) & 15) == 0 && (dastride & 3) == 0)) &&
                (!dp || ((((uintptr_t)dp) & 7) == 0 && (dpstride & 1) == 0)));
   hipStream_t st = ST(stream);
-  float* part = ws;
-  float* k12 = ws + n_img * C * 2;
+  MO_CHECK_ARG((((uintptr_t)ws) & 7) == 0);
+  double* part = reinterpret_cast<double*>(ws);
+  float* k12 = ws + n_img * C * 4;
   const int HW = H * Wd;
   hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img), dim3(HW >= 1024 ? 256 : 64), 0, st, y, istride,
                      C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part);

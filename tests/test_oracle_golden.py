@@ -146,8 +146,8 @@ def test_unet_blocks():
     p = vals('outc', {'conv.weight': (2, 4, 1, 1), 'conv.bias': (2,)})
     run('outc', p, lambda p, x: F.conv2d(x, p['conv.weight'], p['conv.bias']),
         [rand(seed + 10, (2, 4, 8, 8))])
-    # composite blocks (unet.py:95-199): Contraction -> Encoder -> Decoder -> Expansion, 3 counties x 2 days of 32x32
-    NC, H, S = 3, 2, 32
+    # composite blocks (unet.py:95-199): Contraction -> Encoder -> Decoder -> Expansion, 3 counties x 2 days of 64x64
+    NC, H, S = 3, 2, 64
     p = {}
     for nm, sd in zip(('contraction', 'encoder', 'decoder', 'expansion'), G['composite/seeds']):
         keys = [str(k) for k in G[nm + '/keys']]
@@ -162,7 +162,7 @@ def test_unet_blocks():
         assert_close(fms[k], G[f'composite/fm{k}'], 1e-5, 1e-5, f'fm{k}')
     z = unet_ref.fc_block(p, 'encoder', feat, 0.0, True)
     assert_close(z, G['composite/z'], 1e-5, 1e-5, 'encoder')
-    e = unet_ref.fc_block(p, 'decoder', z, 0.0, True).view(NC, H, 64, 2, 2)
+    e = unet_ref.fc_block(p, 'decoder', z, 0.0, True).view(NC, H, 64, 4, 4)
     assert_close(e, G['composite/e'], 1e-5, 1e-5, 'decoder')
     y = unet_ref.expansion(p, e, fms, True)
     assert_close(y, G['composite/y'], 1e-5, 1e-5, 'expansion')

