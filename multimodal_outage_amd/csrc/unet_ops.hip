@@ -647,7 +647,7 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
   if (threadIdx.x == 0) { part[(img * C + c) * 2] = sm[0][0]; part[(img * C + c) * 2 + 1] = sm[1][0]; }
 }
 __global__ void unet_act_bwd_final_kernel(const double* __restrict__ part, long G, int C, int gsize, int HW,
-                                          float* __restrict__ k12 /* [G][C][2] */) {
+                                          double* __restrict__ k12 /* [G][C][2] */) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G * C) return;
   const long g = i / C; const int c = (int)(i - g * C);
@@ -657,10 +657,10 @@ __global__ void unet_act_bwd_final_kernel(const double* __restrict__ part, long 
     const double* p = part + ((g * gsize + j) * C + c) * 2;
     s1 += p[0]; s2 += p[1];
   }
-  k12[i * 2] = (float)(s1 / M);
-  k12[i * 2 + 1] = (float)(s2 / M);
+  k12[i * 2] = s1 / M;
+  k12[i * 2 + 1] = s2 / M;
 }
-__global__ void unet_act_bwd_param_kernel(const float* __restrict__ k12, long G, int C, int gsize, int HW,
+__global__ void unet_act_bwd_param_kernel(const double* __restrict__ k12, long G, int C, int gsize, int HW,
                                           float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -673,7 +673,7 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, const float* __restrict__ sc,
                                           const float* __restrict__ sh, const float* __restrict__ da, long dastride,
-                                          const float* __restrict__ dp, long dpstride, const float* __restrict__ k12,
+                                          const float* __restrict__ dp, long dpstride, const double* __restrict__ k12,
                                           float* __restrict__ dy, long dystride, long total4) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
@@ -688,15 +688,18 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   const float* dpp = dp ? dp + img * dpstride + (long)c * (H / 2) * (W / 2) : nullptr;
   float4 yv; float dz[4];
   unet_dz4(yp, W, yy, q, s, t, dap, dpp, yv, dz);
-  const float k1 = k12[(g * C + c) * 2], k2 = k12[(g * C + c) * 2 + 1], gr = gamma[c] * rs;
+  // the two group means are subtracted in double: rounded to fp32 their error would be the same for every pixel of
+  // the group and come back multiplied by sum(x) in the weight gradient (measured 8e-4 of a gradient's scale)
+  const double k1 = k12[(g * C + c) * 2], k2 = k12[(g * C + c) * 2 + 1];
+  const float gr = gamma[c] * rs;
   float4 o;
-  o.x = gr * (dz[0] - k1 - (yv.x - mu) * rs * k2);
-  o.y = gr * (dz[1] - k1 - (yv.y - mu) * rs * k2);
-  o.z = gr * (dz[2] - k1 - (yv.z - mu) * rs * k2);
-  o.w = gr * (dz[3] - k1 - (yv.w - mu) * rs * k2);
+  o.x = gr * (float)((double)dz[0] - k1 - (double)((yv.x - mu) * rs) * k2);
+  o.y = gr * (float)((double)dz[1] - k1 - (double)((yv.y - mu) * rs) * k2);
+  o.z = gr * (float)((double)dz[2] - k1 - (double)((yv.z - mu) * rs) * k2);
+  o.w = gr * (float)((double)dz[3] - k1 - (double)((yv.w - mu) * rs) * k2);
   *reinterpret_cast<float4*>(dy + img * dystride + ((long)c * H + yy) * W + 4 * q) = o;
 }
-extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * 6 + 64; }   // double partials + k12
+extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * 8 + 64; }   // double partials + double k12
 extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
                                const float* gamma, const float* mean, const float* rstd, const float* sc,
                                const float* sh, const float* da, long dastride, const float* dp, long dpstride,
@@ -710,7 +713,7 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   hipStream_t st = ST(stream);
   MO_CHECK_ARG((((uintptr_t)ws) & 7) == 0);
   double* part = reinterpret_cast<double*>(ws);
-  float* k12 = ws + n_img * C * 4;
+  double* k12 = part + n_img * C * 2;
   const int HW = H * Wd;
   hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img), dim3(HW >= 1024 ? 256 : 64), 0, st, y, istride,
                      C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part);
