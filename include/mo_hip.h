@@ -32,8 +32,10 @@ int mo_version(void);
 int mo_set_option(const char* name, int value);
 
 /* ---- layout: graph_wavenet.py:189/:255 boundary, (B,C,N,T) <-> nbtc -------------------------- */
-int mo_nchw_to_nbtc(const float* x, float* y, int B, int C, int N, int T, void* stream);
-int mo_nbtc_to_nchw(const float* y, float* x, int B, int C, int N, int T, void* stream);
+/* node_new (may be NULL): node_new[v] = internal row block of public node v -- the engine works in a node space
+ * renumbered by graph clusters (blocked SpMM), and the renumbering is folded into these two boundary transposes */
+int mo_nchw_to_nbtc(const float* x, float* y, int B, int C, int N, int T, const int32_t* node_new, void* stream);
+int mo_nbtc_to_nchw(const float* y, float* x, int B, int C, int N, int T, const int32_t* node_new, void* stream);
 
 /* ---- 1x1 conv / Linear (start_conv :117-119,196; skip_convs :164-166,230-236; end_conv_1/2 :174-183,
  *      252-254; residual_convs :159-161,245; Encoder/Decoder fc unet.py:132-136,156-160) -----------

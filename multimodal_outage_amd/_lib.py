@@ -20,8 +20,8 @@ SIGNATURES = {
     'mo_version': (i32, []),
     'mo_set_option': (i32, [C.c_char_p, i32]),
     'mo_unet_set_option': (i32, [C.c_char_p, i32]),
-    'mo_nchw_to_nbtc': (i32, [vp, vp, i32, i32, i32, i32, vp]),
-    'mo_nbtc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'mo_nchw_to_nbtc': (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    'mo_nbtc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     'mo_conv1x1_fwd': (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, i32, vp]),
     'mo_skip_fwd': (i32, [vp, vp, vp, i32, vp, i32, i64, i32, vp, i32, i32, vp, vp]),
     'mo_conv1x1_bwd_data_smallk': (i32, [vp, i32, i64, vp, i32, vp, vp, vp, vp]),

@@ -279,7 +279,8 @@ extern "C" int mo_colsum(const float* X, long P, int C, float* out, float* ws, v
 // layout conversion (B,C,N,T) <-> nbtc rows p=(n*B+b)*T+t of C channels
 // ------------------------------------------------------------------------------------------------
 // One block per (n-tile of 32 positions along the contiguous (n,t) run, b); transposes a [C-chunk 32][32 pos] tile.
-__global__ void nchw_to_nbtc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int N, int T) {
+__global__ void nchw_to_nbtc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int N, int T,
+                                    const int* __restrict__ node_new) {
   __shared__ float tile[32][33];
   const long NT = (long)N * T;
   const int b = blockIdx.z;
@@ -295,11 +296,13 @@ __global__ void nchw_to_nbtc_kernel(const float* __restrict__ x, float* __restri
     long q = q0 + qy; int c = c0 + tx;
     if (q < NT && c < C) {
       long n = q / T; int t = (int)(q - n * T);
+      if (node_new) n = node_new[n];                       // row of the renumbered node space (graph clusters)
       y[((n * B + b) * T + t) * C + c] = tile[tx][qy];
     }
   }
 }
-__global__ void nbtc_to_nchw_kernel(const float* __restrict__ y, float* __restrict__ x, int B, int C, int N, int T) {
+__global__ void nbtc_to_nchw_kernel(const float* __restrict__ y, float* __restrict__ x, int B, int C, int N, int T,
+                                    const int* __restrict__ node_new) {
   __shared__ float tile[32][33];
   const long NT = (long)N * T;
   const int b = blockIdx.z;
@@ -311,6 +314,7 @@ __global__ void nbtc_to_nchw_kernel(const float* __restrict__ y, float* __restri
     float v = 0.f;
     if (q < NT && c < C) {
       long n = q / T; int t = (int)(q - n * T);
+      if (node_new) n = node_new[n];
       v = y[((n * B + b) * T + t) * C + c];
     }
     tile[qy][tx] = v;
@@ -321,16 +325,18 @@ __global__ void nbtc_to_nchw_kernel(const float* __restrict__ y, float* __restri
     if (c < C && q < NT) x[((long)b * C + c) * NT + q] = tile[tx][cy];
   }
 }
-extern "C" int mo_nchw_to_nbtc(const float* x, float* y, int B, int C, int N, int T, void* stream) {
-  MO_CHECK_ARG(x && y && B > 0 && C > 0 && N > 0 && T > 0);
+extern "C" int mo_nchw_to_nbtc(const float* x, float* y, int B, int C, int N, int T, const int32_t* node_new,
+                               void* stream) {
+  MO_CHECK_ARG(x && y && B > 0 && C > 0 && N > 0 && T > 0 && B < 65536);
   dim3 grid(mo_cdiv((long)N * T, 32), mo_cdiv(C, 32), B);
-  hipLaunchKernelGGL(nchw_to_nbtc_kernel, grid, dim3(256), 0, ST(stream), x, y, B, C, N, T);
+  hipLaunchKernelGGL(nchw_to_nbtc_kernel, grid, dim3(256), 0, ST(stream), x, y, B, C, N, T, node_new);
   return mo_launch_status();
 }
-extern "C" int mo_nbtc_to_nchw(const float* y, float* x, int B, int C, int N, int T, void* stream) {
-  MO_CHECK_ARG(x && y && B > 0 && C > 0 && N > 0 && T > 0);
+extern "C" int mo_nbtc_to_nchw(const float* y, float* x, int B, int C, int N, int T, const int32_t* node_new,
+                               void* stream) {
+  MO_CHECK_ARG(x && y && B > 0 && C > 0 && N > 0 && T > 0 && B < 65536);
   dim3 grid(mo_cdiv((long)N * T, 32), mo_cdiv(C, 32), B);
-  hipLaunchKernelGGL(nbtc_to_nchw_kernel, grid, dim3(256), 0, ST(stream), y, x, B, C, N, T);
+  hipLaunchKernelGGL(nbtc_to_nchw_kernel, grid, dim3(256), 0, ST(stream), y, x, B, C, N, T, node_new);
   return mo_launch_status();
 }
 

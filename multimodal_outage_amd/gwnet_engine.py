@@ -296,7 +296,7 @@ class GwnetFunction(torch.autograd.Function):
     """y = gwnet_body(x; params).  x: (B,Cin,N,T) fp32 contiguous on the GPU."""
 
     @staticmethod
-    def forward(ctx, cfg, statics, bn_bufs, training, x, *params):
+    def forward(ctx, cfg, statics, bn_bufs, training, node_new, x, *params):
         p = dict(zip(cfg.names, params))
         dev = x.device
         st = L.stream()
@@ -311,7 +311,8 @@ class GwnetFunction(torch.autograd.Function):
         saved = {}
 
         x_int = _e(G * T, Cin, dev)
-        L.call('mo_nchw_to_nbtc', L.ptr(x), L.ptr(x_int), B, Cin, N, T, st)
+        # node_new (int32 [N] or None): the renumbering of the node axis is folded into the boundary transposes
+        L.call('mo_nchw_to_nbtc', L.ptr(x), L.ptr(x_int), B, Cin, N, T, L.ptr(node_new), st)
         h = _e(G * Tp, 32, dev)
         L.call('mo_conv1x1_fwd', L.ptr(x_int), Cin, Tp, T, -pad, 0, L.ptr(p['start_conv.weight']),
                L.ptr(p['start_conv.bias']), 32, L.ptr(h), G * Tp, 0, 0, st)
@@ -433,9 +434,9 @@ class GwnetFunction(torch.autograd.Function):
         L.call('mo_conv1x1_fwd', L.ptr(r1), cfg.Ce, 0, 0, 0, 0, L.ptr(p['end_conv_2.weight']),
                L.ptr(p['end_conv_2.bias']), cfg.Cout, L.ptr(y_int), P_f, 0, 0, st)
         y = torch.empty((B, cfg.Cout, N, Tf), device=dev, dtype=torch.float32)
-        L.call('mo_nbtc_to_nchw', L.ptr(y_int), L.ptr(y), B, cfg.Cout, N, Tf, st)
+        L.call('mo_nbtc_to_nchw', L.ptr(y_int), L.ptr(y), B, cfg.Cout, N, Tf, L.ptr(node_new), st)
 
-        ctx.cfg, ctx.statics, ctx.training = cfg, statics, training
+        ctx.cfg, ctx.statics, ctx.training, ctx.node_new = cfg, statics, training, node_new
         ctx.dims = (B, N, T, Tp, Tf, G)
         ctx.layers, ctx.x_int, ctx.adp, ctx.adpT, ctx.skip, ctx.r1 = layers, x_int, adp, adpT, skip, r1
         ctx.adp_bf = adp_bf
@@ -474,7 +475,7 @@ class GwnetFunction(torch.autograd.Function):
         P_f = G * Tf
         dy = dy.contiguous()
         dy_int = _e(P_f, cfg.Cout, dev)
-        L.call('mo_nchw_to_nbtc', L.ptr(dy), L.ptr(dy_int), B, cfg.Cout, N, Tf, st)
+        L.call('mo_nchw_to_nbtc', L.ptr(dy), L.ptr(dy_int), B, cfg.Cout, N, Tf, L.ptr(ctx.node_new), st)
         skip, r1 = ctx.skip, ctx.r1
         ws = ws_for(max(cfg.Ce, cfg.Cout), max(cfg.Ce, cfg.Cs), P_f)
         gW2 = gbuf('end_conv_2.weight', p['end_conv_2.weight']); gb2 = gbuf('end_conv_2.bias', p['end_conv_2.bias'])
@@ -695,7 +696,7 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_conv1x1_bwd_data', L.ptr(dxo), 32, G * Tp, L.ptr(Wst), cfg.Cin, L.ptr(dx_int), Tp, T,
                    -pad, None, 0, st)
             dx = torch.empty((B, cfg.Cin, N, T), device=dev, dtype=torch.float32)
-            L.call('mo_nbtc_to_nchw', L.ptr(dx_int), L.ptr(dx), B, cfg.Cin, N, T, st)
+            L.call('mo_nbtc_to_nchw', L.ptr(dx_int), L.ptr(dx), B, cfg.Cin, N, T, L.ptr(ctx.node_new), st)
 
         # ---- adaptive adjacency (graph_wavenet.py:202)
         if dAdp is not None and cfg.overlap and not SERIAL and statics:
@@ -717,5 +718,5 @@ class GwnetFunction(torch.autograd.Function):
         if cfg.grad_ready is not None:
             cfg.grad_ready([n for n in cfg.names if n in gout and gout[n] is not None])
         # gradients written straight into registered flat-buffer views are not handed to autograd
-        return (None, None, None, None, dx) + tuple(
+        return (None, None, None, None, None, dx) + tuple(
             None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)

@@ -221,7 +221,7 @@ class gwnet(nn.Module):
             if order is not None:
                 inv = np.empty_like(order)
                 inv[order] = np.arange(len(order))
-                self._order = (torch.from_numpy(order).to(device), torch.from_numpy(inv).to(device))
+                self._order = (torch.from_numpy(order).to(device), torch.from_numpy(inv.astype(np.int32)).to(device))
             else:
                 self._order = (None, None)
             self._statics_dev = key
@@ -249,9 +249,9 @@ class gwnet(nn.Module):
         statics, order, inverse = self._static_supports(x.device)
         x = x.float()
         if order is not None:
-            # the engine works in the renumbered node space: input nodes and the node embeddings are gathered on the
-            # way in (their gradients return through autograd), the output is gathered back
-            x = x.index_select(2, order)
+            # the engine works in the renumbered node space: the input / output node axes are renumbered inside the
+            # engine's boundary transposes (mo_nchw_to_nbtc / mo_nbtc_to_nchw take the map); only the (N,10) node
+            # embeddings are gathered here (their gradients return through autograd)
             for k, name in enumerate(names):
                 if name == 'nodevec1':
                     params[k] = params[k].index_select(0, order)
@@ -259,8 +259,7 @@ class gwnet(nn.Module):
                     params[k] = params[k].index_select(1, order)
             if cfg.grad_out is not None:
                 cfg.grad_out = {k: v for k, v in cfg.grad_out.items() if k not in ('nodevec1', 'nodevec2')}
-        y = GwnetFunction.apply(cfg, statics, bn_bufs, self.training, x, *params)
-        return y.index_select(2, inverse) if order is not None else y
+        return GwnetFunction.apply(cfg, statics, bn_bufs, self.training, inverse, x, *params)
 
     def forward(self, input):
         if input.dim() == 3:

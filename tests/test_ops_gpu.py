@@ -60,10 +60,19 @@ def test_layout_roundtrip(L, B, C, N, T):
     x = rand(1, (B, C, N, T))
     xd = dev(x)
     y = torch.empty(N * B * T, C, device='cuda')
-    L.call('mo_nchw_to_nbtc', L.ptr(xd), L.ptr(y), B, C, N, T, L.stream())
+    L.call('mo_nchw_to_nbtc', L.ptr(xd), L.ptr(y), B, C, N, T, None, L.stream())
     assert torch.equal(y.cpu(), nbtc(x))
     z = torch.empty_like(xd)
-    L.call('mo_nbtc_to_nchw', L.ptr(y), L.ptr(z), B, C, N, T, L.stream())
+    L.call('mo_nbtc_to_nchw', L.ptr(y), L.ptr(z), B, C, N, T, None, L.stream())
+    assert torch.equal(z.cpu(), x)
+    # with a node renumbering folded in: internal node block new = node_new[public node] (the engine's cluster order)
+    order = torch.from_numpy(np.random.RandomState(N).permutation(N))            # order[new] = old
+    inv = torch.empty(N, dtype=torch.int32)
+    inv[order] = torch.arange(N, dtype=torch.int32)
+    invd = dev(inv)
+    L.call('mo_nchw_to_nbtc', L.ptr(xd), L.ptr(y), B, C, N, T, L.ptr(invd), L.stream())
+    assert torch.equal(y.cpu(), nbtc(x.index_select(2, order)))
+    L.call('mo_nbtc_to_nchw', L.ptr(y), L.ptr(z), B, C, N, T, L.ptr(invd), L.stream())
     assert torch.equal(z.cpu(), x)
 
 
