@@ -26,8 +26,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_NODES, C_IN, T_IN, OUT_DIM, KSIZE = 3000, 32, 12, 12, 2
-# compulsory fp32 tensor traffic per window, forward; fwd+bwd counted as 3x
-ALG_BYTES_FWD_PER_WINDOW = 768.7e6
+# compulsory tensor traffic per window, forward (all-fp32 / all-bf16 figures of the survey);
+# fwd+bwd counted as 3x.  The benchmark's throughput mode stores a MIX of fp32 and bf16 tensors: alg_bytes() below
+# re-does the App. D accounting tensor by tensor with the element sizes the engine really stores.
+SURVEY_BYTES_FWD_PER_WINDOW = {'f32': 768.7e6, 'bf16': 384.4e6}
+# UNet conv stack, 13x256x256 tile, forward, per-op in+out accounting (fp32); x3 with backward
+UNET_BYTES_FWD_PER_TILE = 29.7e6
+UNET_FLOP_FWD_PER_TILE = 0.444e9
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBPS = 8000.0
@@ -46,6 +51,39 @@ def pmc_traffic(dtype, batch):
         return None
 
 
+def alg_bytes(dtype):
+    """App. D accounting (materialised tensors cross HBM once per producer and once per consumer, elementwise chains
+    fused, concat never materialised, x2 of the static supports never materialised) per window, forward, with the
+    element size of every tensor as the engine stores it.  Returns (block, step): `block` = the fused gated-TCN +
+    diffusion-GCN block's own HBM-bound part (TCN, static-support hops, mlp + residual + BatchNorm); `step` adds the
+    adaptive support's hop tensors (moved by the dense-product kernels), the skip path with the exact crop
+    optimisation, start conv, head and the adaptive adjacency."""
+    bf = dtype == 'bf16'
+    e_h = 4                       # layer input x_in / pre-BN h / BN output: fp32 in both modes
+    e_gw = 4 + (2 if bf else 0)   # gated TCN output g: fp32 (+ the bf16 copy the node-axis products read)
+    e_gs = 2 if bf else 4         # g as the node-axis products read it
+    e_x = 2 if bf else 4          # diffusion intermediates x1 / x2
+    S_static, S = 2, 3
+    touts, tins, t = [], [], 13
+    for d in [1, 2] * 4:
+        tins.append(t); t -= d * (KSIZE - 1); touts.append(t)
+    block = step = 0.0
+    for Tin, To in zip(tins, touts):
+        b = 32 * Tin * e_h                                   # TCN reads x_in
+        b += 32 * To * e_gw                                  # writes g
+        b += S_static * 32 * To * (e_gs + e_x)               # static hop 1: read g, write x1
+        b += 32 * To * (4 + 2 * S * e_x + e_h + e_h)         # mlp: g, (x1 direct + x1 gathered | x1, x2 adaptive), x_in crop; write h
+        b += 32 * To * 2 * e_h                               # BatchNorm apply: read h, write x_out
+        block += b
+        step += b + 32 * To * (e_gs + 3 * e_x)               # adaptive hops: read g, write x1, read x1, write x2
+        step += 32 * To * 4                                  # skip conv reads g
+    Tf = touts[-1]
+    step += 256 * Tf * 4 * 2                                 # skip written once (crop optimisation) and read by the head
+    step += (C_IN * T_IN + 32 * 13) * 4                      # start conv in + out
+    step += (512 * Tf * 2 + OUT_DIM * Tf) * 4                # head: r1 written + read, y written
+    return block * N_NODES, step * N_NODES
+
+
 def host_cores():
     """Cores this process may really use: cgroup CPU quota if set, else affinity, capped at the
     16-core share of a one-GPU box (oversubscribing the quota makes the CPU leg crawl)."""
@@ -57,6 +95,34 @@ def host_cores():
     except Exception:
         pass
     return max(1, min(n, 16))
+
+
+def gpu_matched_loss(schema, supports, x, y, n_steps):
+    """Matched-loss check of the CPU leg: the HIP path from the same seeded weights on the same windows for the same
+    number of Adam steps (dropout 0.3 on both sides, so the masks -- torch's CPU generator there, the engine's counter
+    hash here -- differ and the losses agree statistically, not bitwise).  Returns {mode: loss after n_steps}."""
+    from oracle import params as P
+    from multimodal_outage_amd.models.graph_wavenet import gwnet
+    from multimodal_outage_amd.trainer import FlatTrainer
+    out = {}
+    for mode in ('f32', 'bf16'):
+        torch.manual_seed(42)
+        m = gwnet('cpu', num_nodes=N_NODES, dropout=0.3, supports=supports, in_dim=C_IN, out_dim=OUT_DIM,
+                  kernel_size=KSIZE, blocks=4, layers=2)
+        P.load_into(m, P.seeded_values(schema, 42))
+        m = m.cuda().train()
+        m.dense_dtype = mode
+        tr = FlatTrainer(m, lr=1e-3).attach()
+        xd, yd = x.cuda(), y.cuda()
+        for _ in range(n_steps):
+            tr.zero_grad()
+            loss = F.mse_loss(m(xd), yd)
+            loss.backward()
+            tr.allreduce()
+            tr.step()
+        out[mode] = round(float(loss.detach()), 6)
+        del m, tr
+    return out
 
 
 def cpu_baseline(supports, max_steps=5, batch=4, budget_s=25.0):
@@ -85,18 +151,20 @@ def cpu_baseline(supports, max_steps=5, batch=4, budget_s=25.0):
         return float(loss.detach())
 
     t0 = time.perf_counter()
-    one()   # warm-up
+    last = one()   # warm-up
     warm = time.perf_counter() - t0
     print(f'[bench] cpu_baseline warm-up step {warm:.1f} s on {cores} threads', file=sys.stderr, flush=True)
     steps, t0 = 0, time.perf_counter()
     while steps < max_steps and (steps == 0 or time.perf_counter() - t0 + warm < budget_s):
-        one()
+        last = one()
         steps += 1
         print(f'[bench] cpu_baseline step {steps}: {time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 4), "unit": "windows/s", "cores": cores, "kind": "port",
             "sample": f"{steps} step(s) of fwd+MSE+bwd+Adam at batch {batch} (N=3000,T=12,C=32,K=2, "
-                      f"dropout 0.3) after 1 warm-up step; {dt:.1f} s"}
+                      f"dropout 0.3) after 1 warm-up step; {dt:.1f} s",
+            "loss_after_steps": round(last, 6), "steps_incl_warmup": steps + 1,
+            "gpu_loss_same_steps": gpu_matched_loss(schema, supports, x, y, steps + 1)}
 
 
 def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=256):
@@ -155,7 +223,17 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
              "device_allocs_in_pass": int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),
              "device_frees_in_pass": int(ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0))}
     tiles = batch * 67 * horizon
-    return {"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(world * tiles * steps / dt, 1), "unit": "tiles/s",
+    tps = world * tiles * steps / dt
+    # conv-stack roofline of this leg (29.7 MB fp32 / 0.444 GFLOP per 13x256x256 tile forward, per-op in+out
+    # accounting, x3 with backward) over the WHOLE step time (FC bottleneck, the 67-node Graph WaveNet, loss and Adam
+    # are inside it); per-kernel durations: profiles/r02_unet_c3_kernel_stats.csv
+    scale = (cin * size * size) / (13.0 * 256 * 256) if (cin, size) != (13, 256) else 1.0
+    gbs = 3 * UNET_BYTES_FWD_PER_TILE * scale * tps / world / 1e9
+    roof = {"bound": "hbm", "kernel": "UNet conv stack (all kernels of the Modified_UNET step)",
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBPS, 4),
+            "algorithmic_MB_per_tile_fwd": round(UNET_BYTES_FWD_PER_TILE * scale / 1e6, 2),
+            "vector_TFLOPs": round(3 * UNET_FLOP_FWD_PER_TILE * scale * tps / world / 1e12, 2), "traffic": None}
+    return {"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(tps, 1), "unit": "tiles/s", "roofline": roof,
             "ms_per_step": round(dt / steps * 1e3, 2), "tiles_per_step_per_gpu": tiles, "steps": steps, "warmup": warmup,
             "trace": trace, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Modified_UNET fwd+MSE+bwd+Adam on ({batch},67,{horizon},{cin},{size},{size}) tiles",
@@ -250,15 +328,35 @@ def main():
     dt = time.perf_counter() - t0
     prof, engine.PROFILE = engine.PROFILE, None
     loss = float(sums[0].item()) / n_out
-    # the same kernels without the side-stream overlap (2 extra untimed-for-throughput steps): their
-    # un-contended duration, reported beside the timed-region figure
+    # the same kernels without any side-stream overlap (2 extra steps, not part of `value`): every C-ABI launch of the
+    # step is bracketed by HIP events on its (single) stream, so that each kernel family's un-contended time is known --
+    # the dense products' (`*_serial`) and the fused gated-TCN + diffusion-GCN block's own HBM-bound kernels
     engine.SERIAL = True
     engine.PROFILE = []
-    for _ in range(2):
+    per_call = []
+    real_call = L.call
+
+    def timed_call(name, *a):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_call(name, *a)
+        e1.record()
+        per_call.append((name, e0, e1))
+    L.call = timed_call
+    n_serial = 2
+    for _ in range(n_serial):
         step()
     sync()
+    L.call = real_call
     prof_serial, engine.PROFILE = engine.PROFILE, None
     engine.SERIAL = False
+    by_name = {}
+    for name, e0, e1 in per_call:
+        by_name[name] = by_name.get(name, 0.0) + e0.elapsed_time(e1) / n_serial
+    BLOCK = ('mo_tcn_fwd', 'mo_tcn_bwd', 'mo_tcn_pack_weights', 'mo_spmm_blk', 'mo_spmm_csr', 'mo_gcn_mlp_fwd',
+             'mo_gcn_mlp_bwd', 'mo_bn_finalize', 'mo_bn_bwd')
+    block_ms = sum(by_name.get(k, 0.0) for k in BLOCK)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -281,26 +379,42 @@ def main():
                 "frac": round(ach / peak, 4),
                 "launches": len(prof), "avg_launch_ms": round(gemm_ms / n_launch, 4),
                 "avg_launch_gflop": round(gemm_flops / n_launch / 1e9, 3),
-                "note": "timed region: the product runs on a side stream beside the HBM-bound sparse branch and the "
-                        "weight-gradient lane, so its launches are stretched by contention; *_serial = same launches "
-                        "with the overlap disabled (2 extra steps after the timed region); peak is the spec-sheet dense "
-                        "bf16 figure at 2.4 GHz -- under this kernel the chip is power-limited and holds ~1.54 GHz "
-                        "(tools/clock_probe: 2402 MHz idle, 1539 MHz beside the GEMM), i.e. 1.6 PFLOP/s at the sustained clock",
+                "note": "timed region: the data-path products run on the main stream, the two dA accumulations of a "
+                        "layer on a second stream beside the main chain (their 144-tile grids leave 112 CUs to it) and "
+                        "the weight-gradient kernels on a third; *_serial = same launches with every overlap disabled "
+                        "(2 extra steps after the timed region); peak is the spec-sheet dense bf16 figure at 2.4 GHz -- "
+                        "under this kernel the chip is power-limited and holds ~1.54 GHz (tools/clock_probe: 2402 MHz "
+                        "idle, 1539 MHz beside the GEMM), i.e. 1.6 PFLOP/s at the sustained clock",
                 "achieved_serial": round(ser_ach, 3), "frac_serial": round(ser_ach / peak, 4),
                 "avg_launch_ms_serial": round(ser_ms / max(len(prof_serial), 1), 4),
                 "traffic": pmc_traffic(args.dtype, B)}
-    # secondary: the whole step (TCN gate, SpMM, mlp+BN, skip, head, their backward AND the dense products, which
-    # overlap the sparse branch on a side stream) priced against the HBM roofline with the compulsory-traffic
-    # model of SURVEY.md 8(d) (fp32 tensors, fwd+bwd = 3x forward): a lower bound on the HBM fraction of the
-    # fused gated-TCN + diffusion-GCN block, since the MFMA-bound products are inside the denominator
+    # the fused gated-TCN + diffusion-GCN block (north star: >= 40 % of the HBM roofline): algorithmic bytes of the
+    # block's own HBM-bound kernels for the dtype mix actually stored (alg_bytes), over their un-contended HIP-event
+    # time in the serial steps; and the whole step priced the same way (the MFMA-bound products are in its denominator)
     step_ms = dt / args.steps * 1e3
-    alg_gb = 3 * ALG_BYTES_FWD_PER_WINDOW * B / 1e9
-    hbm_block = {"bound": "hbm", "what": "whole training step vs compulsory tensor traffic (SURVEY 8d: 768.7 MB fp32 "
-                                         "per window forward, x3 with backward)",
-                 "algorithmic_GB_per_step": round(alg_gb, 3), "ms_per_step": round(step_ms, 3),
-                 "dense_product_ms_per_step": round(gemm_ms / args.steps, 3),
-                 "achieved": round(alg_gb / (step_ms * 1e-3), 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                 "frac": round(alg_gb / (step_ms * 1e-3) / PEAK_HBM_GBPS, 4)}
+    blk_b, stp_b = alg_bytes(args.dtype)
+    blk_gb, stp_gb = 3 * blk_b * B / 1e9, 3 * stp_b * B / 1e9
+    blk_ach = blk_gb / (block_ms * 1e-3) if block_ms > 0 else 0.0
+    hbm_block = {"bound": "hbm",
+                 "what": "fused gated-TCN + diffusion-GCN block: its own HBM-bound kernels (TCN fwd/bwd, static-support "
+                         "SpMM, mlp + residual + BatchNorm fwd/bwd, their weight gradients) un-contended (serial steps, "
+                         "HIP events per launch) vs the App. D compulsory traffic of exactly those tensors at the "
+                         "element sizes the engine stores (fwd x3 for fwd+bwd)",
+                 "dtype_mix": ("g fp32 + bf16 copy, x1/x2 and their gradients bf16, h / BatchNorm / skip / head fp32"
+                               if args.dtype == 'bf16' else "all fp32"),
+                 "algorithmic_MB_per_window_fwd": round(blk_b / 1e6, 1),
+                 "algorithmic_GB_per_step": round(blk_gb, 3), "kernel_ms_per_step": round(block_ms, 3),
+                 "achieved": round(blk_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                 "frac": round(blk_ach / PEAK_HBM_GBPS, 4),
+                 "kernel_ms": {k: round(v, 3) for k, v in sorted(by_name.items(), key=lambda kv: -kv[1])[:14]},
+                 "whole_step": {"algorithmic_MB_per_window_fwd": round(stp_b / 1e6, 1),
+                                "algorithmic_GB_per_step": round(stp_gb, 3), "ms_per_step": round(step_ms, 3),
+                                "achieved": round(stp_gb / (step_ms * 1e-3), 1),
+                                "frac": round(stp_gb / (step_ms * 1e-3) / PEAK_HBM_GBPS, 4),
+                                "survey_all_fp32_MB": SURVEY_BYTES_FWD_PER_WINDOW['f32'] / 1e6,
+                                "survey_all_bf16_MB": SURVEY_BYTES_FWD_PER_WINDOW['bf16'] / 1e6,
+                                "note": "the MFMA-bound dense products are inside this step time; the survey's figures "
+                                        "are without the skip-crop optimisation and for uniform element sizes"}}
 
     line = {"metric": "train windows/sec (gwnet N=3k,T=12)", "value": round(windows_per_s, 3),
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -115,6 +115,12 @@ class StaticSupport:
 
     def _pack(self, a, device, blocked):
         rowptr, cols, vals = csr_from_dense(a)
+        # the kernels trust these arrays (a gather through a bad column index is a device memory fault, not an MO_E*
+        # return -- round 1's only GPU abort was a test helper handing the C-ABI index arrays that had been freed):
+        # validate once on the host, and keep the device copies alive as attributes of this object
+        if not (rowptr[0] == 0 and (np.diff(rowptr) >= 0).all() and rowptr[-1] == len(cols)
+                and (len(cols) == 0 or (cols.min() >= 0 and cols.max() < self.n))):
+            raise ValueError('StaticSupport: malformed CSR')
         blk = None
         if blocked:
             lcol, uptr, usrc, umax = block_unions(rowptr, cols, self.n)

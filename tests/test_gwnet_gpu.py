@@ -571,3 +571,26 @@ def test_resume_from_reference_lightning_checkpoint():
             continue
         # one Adam step of size lr ~ 1e-3: parameters must agree to a small fraction of that step
         assert_close(got, ref, 2e-5, 1e-5, 'param after resumed step ' + k)
+
+
+def test_gwnet_batch_limit_of_32bit_row_offsets(c2_oracle):
+    """The row-streaming kernels address rows through 32-bit buffer-descriptor offsets: N*B*T_in rows of up to 256
+    bytes must stay below 2^32 (csrc/gwnet_ops.hip rs_tcn_ok), i.e. B <= 430 at N=3000, T_in=13 -- the limit behind
+    round 1's rejected B=512 run.  The largest accepted batch runs (forward, eval mode: training at that size needs
+    more than the 288 GB of HBM, which is the practical limit, ~B=330) and reproduces a batch of 2; one more window is
+    refused with the library's error code, not launched."""
+    O = c2_oracle
+    m = _model(C2, O['sup']).eval()
+    m.dense_dtype = 'bf16'
+    x2 = O['x'].cuda()
+    with torch.no_grad():
+        y2 = m(x2)
+        x = x2.repeat(215, 1, 1, 1)                                     # 430 windows
+        assert x.shape[0] * 3000 * 13 * 256 < 0xFFFFF000 <= (x.shape[0] + 1) * 3000 * 13 * 256
+        y = m(x)
+        assert torch.isfinite(y).all()
+        scale = float(y2.abs().max())
+        assert float((y[-2:] - y2).abs().max()) <= 1e-3 * scale and float((y[:2] - y2).abs().max()) <= 1e-3 * scale
+        del y
+        with pytest.raises(RuntimeError, match='unsupported configuration'):
+            m(torch.cat([x, x2[:1]]))
