@@ -204,6 +204,17 @@ int mo_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
  * `gsize` consecutive images: the reference calls each block once per county on `horizon` images, so
  * train-mode BatchNorm statistics are per (batch element, county). */
 
+/* Activation storage ("bf16 mode" of BASELINE config 3): a `dtypes` argument says which of an entry point's activation
+ * tensors are stored as bf16 instead of fp32 (the pointer types stay float*; strides count ELEMENTS).  Arithmetic is
+ * fp32 either way.  bf16 storage exists on the direct / streaming kernels (3x3 convs with <= 32 output channels at
+ * >= 32x32 pixels, the MFMA weight gradient at W % 64 == 0 and H % 8 == 0, thin 1x1 convs, activation kernels);
+ * any other shape returns MO_EUNSUPPORTED when a flag is set. */
+#define MO_BF_IN0 1   /* first input view (mo_unet_act_bwd: y) */
+#define MO_BF_IN1 2   /* second input view (mo_unet_act_bwd: da) */
+#define MO_BF_OUT 4   /* the output tensor (mo_unet_act_bwd: dy) */
+#define MO_BF_DY 8    /* the output-gradient operand of a weight / data gradient */
+#define MO_BF_DP 16   /* mo_unet_act_bwd: the pooled gradient dp */
+
 /* DoubleConv conv (unet.py:44,47; nn.Conv2d k=3 pad=1 bias=False) over the channel concat of up to two
  * activated views (the skip/up cat of unet.py:83): out[img][co] raw. W: (Co, C0+C1, 3, 3). */
 int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, const float* sh0, int relu0,
@@ -211,7 +222,7 @@ int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, co
                    int gsize, const float* W, int Co, long n_img, int H, int Wd, float* out, long ostride,
                    float* stats /* optional [n_img][tiles][Co][2] per-tile (sum, sumsq) of out, tiles =
                    mo_conv3x3_stats_tiles(): the BatchNorm statistics come out of the conv's epilogue; NULL: none */,
-                   void* stream);
+                   int dtypes /* MO_BF_IN0 | MO_BF_IN1 | MO_BF_OUT */, void* stream);
 /* per-image statistics rows mo_conv3x3_fwd writes for this shape (0: none -- run mo_nchw_stats on the output) */
 int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
 /* Wf[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]; the data gradient is mo_conv3x3_fwd(dy, Wf). */
@@ -221,17 +232,19 @@ long mo_unet_wgrad_ws_floats(int M, int N, long P);
 int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, const float* in0, int C0, long istride0,
                           const float* sc0, const float* sh0, int relu0, const float* in1, int C1,
                           long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
-                          long n_img, int H, int Wd, float* dW, float* ws, void* stream);
+                          long n_img, int H, int Wd, float* dW, float* ws,
+                          int dtypes /* MO_BF_DY | MO_BF_IN0 | MO_BF_IN1 */, void* stream);
 /* OutConv (unet.py:86-92): 1x1 conv with bias on an activated NCHW view */
 int mo_nchw_conv1x1_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                         int gsize, const float* W, const float* b, int Co, long n_img, int HW, float* out,
-                        long ostride, void* stream);
+                        long ostride, int dtypes /* MO_BF_IN0 | MO_BF_OUT */, void* stream);
 int mo_nchw_conv1x1_bwd_data(const float* dout, long dostride, int Co, const float* W, int Ci, long n_img,
-                             int HW, float* din, long distride, void* stream);
+                             int HW, float* din, long distride, int dtypes /* MO_BF_DY | MO_BF_OUT */, void* stream);
 /* db (may be NULL): the bias gradient, sum of dout over images and pixels */
 int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride,
                                int Ci, const float* sc, const float* sh, int relu, int gsize, long n_img,
-                               int HW, float* dW, float* db, float* ws, void* stream);
+                               int HW, float* dW, float* db, float* ws, int dtypes /* MO_BF_DY | MO_BF_IN0 */,
+                               void* stream);
 /* Up.up (unet.py:71): ConvTranspose2d(Ci, Co, k=2, s=2) with bias; W (Ci, Co, 2, 2); H,Wd = input size */
 int mo_convt2x2_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                     int gsize, const float* W, const float* b, int Co, long n_img, int H, int Wd, float* out,
@@ -252,14 +265,16 @@ int mo_group_bn_finalize(const float* stats /* [n_img][ntile][C][2] */, long n_i
                          void* stream);
 /* materialise relu(y*sc+sh), optionally 2x2 max-pooled (Down, unet.py:60) */
 int mo_unet_act(const float* y, long istride, int C, long n_img, int H, int Wd, const float* sc,
-                const float* sh, int gsize, int pool, float* out, long ostride, void* stream);
+                const float* sh, int gsize, int pool, float* out, long ostride,
+                int dtypes /* MO_BF_IN0 | MO_BF_OUT */, void* stream);
 /* backward through ReLU + group BatchNorm (+ max-pool routing of dp); da = gradient w.r.t. the activated
  * view, dp = gradient w.r.t. its pooled version (either may be NULL); ws: mo_unet_act_bwd_ws_floats */
 long mo_unet_act_bwd_ws_floats(long n_img, int C);
 int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
                     const float* gamma, const float* mean, const float* rstd, const float* sc,
                     const float* sh, const float* da, long dastride, const float* dp, long dpstride,
-                    float* dy, long dystride, float* dgamma, float* dbeta, float* ws, void* stream);
+                    float* dy, long dystride, float* dgamma, float* dbeta, float* ws,
+                    int dtypes /* MO_BF_IN0 (y) | MO_BF_IN1 (da) | MO_BF_DP | MO_BF_OUT (dy) */, void* stream);
 /* out[c] = sum over images and pixels (bias gradients); ws: n_img*C*2 floats */
 int mo_nchw_channel_sum(const float* x, long istride, int C, long n_img, int HW, float* out, float* ws,
                         void* stream);

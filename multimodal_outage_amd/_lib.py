@@ -62,24 +62,24 @@ SIGNATURES = {
     'mo_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, vp]),
     # ---- UNet
     'mo_conv3x3_fwd': (i32, [vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32, vp, i32, i64, i32, i32,
-                             vp, i64, vp, vp]),
+                             vp, i64, vp, i32, vp]),
     'mo_conv3x3_stats_tiles': (i32, [i32, i64, i32, i32]),
     'mo_conv3x3_flip_weights': (i32, [vp, i32, i32, vp, vp]),
     'mo_unet_wgrad_ws_floats': (i64, [i32, i32, i64]),
     'mo_conv3x3_bwd_weight': (i32, [vp, i64, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32,
-                                    i64, i32, i32, vp, vp, vp]),
-    'mo_nchw_conv1x1_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, vp, i64, vp]),
-    'mo_nchw_conv1x1_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, vp, i64, vp]),
-    'mo_nchw_conv1x1_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, vp, vp, vp, vp]),
+                                    i64, i32, i32, vp, vp, i32, vp]),
+    'mo_nchw_conv1x1_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, vp, i64, i32, vp]),
+    'mo_nchw_conv1x1_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, vp, i64, i32, vp]),
+    'mo_nchw_conv1x1_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
     'mo_convt2x2_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, i32, vp, i64, vp]),
     'mo_convt2x2_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, i32, vp, i64, vp]),
     'mo_convt2x2_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp]),
     'mo_nchw_stats': (i32, [vp, i64, i32, i64, i32, vp, vp]),
     'mo_group_bn_finalize': (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
-    'mo_unet_act': (i32, [vp, i64, i32, i64, i32, i32, vp, vp, i32, i32, vp, i64, vp]),
+    'mo_unet_act': (i32, [vp, i64, i32, i64, i32, i32, vp, vp, i32, i32, vp, i64, i32, vp]),
     'mo_unet_act_bwd_ws_floats': (i64, [i64, i32]),
     'mo_unet_act_bwd': (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64,
-                              vp, vp, vp, vp]),
+                              vp, vp, vp, i32, vp]),
     'mo_nchw_channel_sum': (i32, [vp, i64, i32, i64, i32, vp, vp, vp]),
     'mo_maxpool2_bwd': (i32, [vp, i64, i32, i64, i32, i32, vp, i64, vp, i64, vp]),
     'mo_dropout': (i32, [vp, vp, i64, u32, u32, f32, vp]),
@@ -116,6 +116,9 @@ def check(code, what=''):
     if code != 0:
         msg = load().mo_strerror(code).decode()
         raise RuntimeError(f'mo_hip {what}: {msg} (code {code})')
+
+
+BF_IN0, BF_IN1, BF_OUT, BF_DY, BF_DP = 1, 2, 4, 8, 16     # `dtypes` flags of the UNet entry points (include/mo_hip.h)
 
 
 def ptr(t):

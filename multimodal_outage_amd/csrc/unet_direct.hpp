@@ -9,6 +9,31 @@
 
 #define UD_CK 8          // input channels per LDS stage
 
+// ---- activation storage: fp32, or bf16 ("bf16 mode" of BASELINE config 3: the raw conv outputs and their gradients at
+// the large resolutions live in HBM as bf16, every kernel widens on load, computes in fp32 and narrows on store with
+// round-to-nearest-even).  idx = element index; idx % 4 == 0 for the 4-wide forms.
+__device__ __forceinline__ float ua_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float ua_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float4 ua_ld4(const void* base, long idx, int bf) {
+  if (bf) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    return make_float4(ua_lo(u.x), ua_hi(u.x), ua_lo(u.y), ua_hi(u.y));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+__device__ __forceinline__ float ua_ld1(const void* base, long idx, int bf) {
+  if (bf) return __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(base)[idx]) << 16);
+  return reinterpret_cast<const float*>(base)[idx];
+}
+__device__ __forceinline__ unsigned ua_pack2(float a, float b) {
+  __bf16 ta = (__bf16)a, tb = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ta) | ((unsigned)__builtin_bit_cast(unsigned short, tb) << 16);
+}
+__device__ __forceinline__ void ua_st4(void* base, long idx, float4 v, int bf) {
+  if (bf) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = make_uint2(ua_pack2(v.x, v.y), ua_pack2(v.z, v.w));
+  else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
+}
+
 struct UdConvArgs {
   const float* in0; const float* sc0; const float* sh0; long is0; int C0, relu0;
   const float* in1; const float* sc1; const float* sh1; long is1; int C1, relu1;
@@ -16,6 +41,7 @@ struct UdConvArgs {
   float* out; long os;
   int Co, H, Wd, gsize;
   float* stats;            // optional [img][tile][Co][2]: per-tile (sum, sum of squares) of the raw outputs
+  int bf0, bf1, bfo;       // storage of in0 / in1 / out: 0 fp32, 1 bf16 (strides are in ELEMENTS either way)
 };
 
 // activated value of channel c (of the concat) at (y, x) of image img; zero outside the image
@@ -25,7 +51,7 @@ __device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, long grp,
   const int cc = first ? c : c - a.C0;
   const float* base = first ? a.in0 : a.in1;
   const long is = first ? a.is0 : a.is1;
-  float v = base[img * is + ((long)cc * a.H + y) * a.Wd + x];
+  float v = ua_ld1(base, img * is + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
   const float* sc = first ? a.sc0 : a.sc1;
   if (sc) {
     const float* sh = first ? a.sh0 : a.sh1;
@@ -56,7 +82,7 @@ __device__ __forceinline__ void ud_stage_halo(float* tile /* [nc][TH+2][LDT] */,
       const int cc = first ? cg : cg - a.C0;
       const float* base = first ? a.in0 : a.in1;
       const long is = first ? a.is0 : a.is1;
-      v = *reinterpret_cast<const float4*>(&base[img * is + ((long)cc * a.H + y) * a.Wd + x]);
+      v = ua_ld4(base, img * is + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
       const float* sc = first ? a.sc0 : a.sc1;
       if (sc) {
         const float* sh = first ? a.sh0 : a.sh1;
@@ -129,8 +155,8 @@ __global__ __launch_bounds__(256) void ud_conv3x3_kernel(UdConvArgs a) {
 #pragma unroll
     for (int co = 0; co < CO; ++co)
       if (co < a.Co)
-        *reinterpret_cast<float4*>(&a.out[img * a.os + ((long)co * a.H + y) * a.Wd + x]) =
-            make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+        ua_st4(a.out, img * a.os + ((long)co * a.H + y) * a.Wd + x,
+               make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]), a.bfo);
   }
   if (a.stats) {
     // BatchNorm statistics of this tile straight from the accumulators (fixed order: 4 pixels, wave shuffles, the four
@@ -171,6 +197,7 @@ struct UdWgradArgs {
   float* slab;             // [nz][Co*Ci*9]
   int Co, H, Wd, gsize;
   long n_img; int img_per_wg, n_cichunk;
+  int bfd, bf0, bf1;       // storage of dy / in0 / in1 (0 fp32, 1 bf16); the VALU kernel below takes fp32 only
 };
 
 template <int TH, int TW>
@@ -192,6 +219,7 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
   ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
   ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
   ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize; ca.stats = nullptr;
+  ca.bf0 = a.bf0; ca.bf1 = a.bf1; ca.bfo = 0;
 
   float acc[UD_WC][UD_WI][9];
 #pragma unroll
@@ -296,6 +324,7 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
   ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
   ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
   ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize; ca.stats = nullptr;
+  ca.bf0 = a.bf0; ca.bf1 = a.bf1; ca.bfo = 0;
 
   // per-lane fragment geometry
   int abase[MB]; float amask[MB];
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
         const int cc = first ? cg : cg - a.C0;
         const float* base = first ? a.in0 : a.in1;
         const long is = first ? a.is0 : a.is1;
-        v = *reinterpret_cast<const float4*>(&base[img * is + ((long)cc * a.H + y) * a.Wd + x]);
+        v = ua_ld4(base, img * is + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
         const float* sc = first ? a.sc0 : a.sc1;
         if (sc) {
           const float* sh = first ? a.sh0 : a.sh1;
@@ -360,7 +389,7 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
     for (int idx = tid; idx < a.Co * UW_TH * (UW_TW / 4); idx += 256) {
       const int co = idx / (UW_TH * (UW_TW / 4)), r = idx - co * (UW_TH * (UW_TW / 4));
       const int yy = r / (UW_TW / 4), q = r - yy * (UW_TW / 4);
-      const float4 d = *reinterpret_cast<const float4*>(&a.dy[img * a.dys + ((long)co * a.H + y0 + yy) * a.Wd + x0 + 4 * q]);
+      const float4 d = ua_ld4(a.dy, img * a.dys + ((long)co * a.H + y0 + yy) * a.Wd + x0 + 4 * q, a.bfd);
       *reinterpret_cast<float4*>(&dys[co * UW_DPS + yy * UW_TW + 4 * q]) = d;
     }
     __syncthreads();

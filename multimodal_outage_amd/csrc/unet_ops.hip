@@ -13,6 +13,12 @@
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
+// storage flags of the `dtypes` arguments (include/mo_hip.h)
+#define MO_BF_IN0 1
+#define MO_BF_IN1 2
+#define MO_BF_OUT 4
+#define MO_BF_DY 8
+#define MO_BF_DP 16
 static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 = previous VALU / split-K weight gradients
 extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!name) return MO_EINVAL;
@@ -154,7 +160,7 @@ extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd) {
 extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, const float* sh0, int relu0,
                               const float* in1, int C1, long istride1, const float* sc1, const float* sh1, int relu1,
                               int gsize, const float* W, int Co, long n_img, int H, int Wd, float* out, long ostride,
-                              float* stats, void* stream) {
+                              float* stats, int dtypes, void* stream) {
   MO_CHECK_ARG(in0 && W && out && C0 > 0 && C1 >= 0 && Co > 0 && n_img > 0 && H > 0 && Wd > 0 && (Wd % 4) == 0);
   MO_CHECK_ARG(C1 == 0 || in1);
   const long P = n_img * H * Wd;
@@ -164,6 +170,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
   if (ud_conv_direct(in0, istride0, in1, C1, istride1, Co, n_img, H, Wd, out, ostride)) {
     UdConvArgs a;
     a.stats = stats;
+    a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0; a.bfo = (dtypes & MO_BF_OUT) != 0;
     a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
     a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
     a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
@@ -176,6 +183,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
 #undef UD_LAUNCH
     return mo_launch_status();
   }
+  if (dtypes) return MO_EUNSUPPORTED;            // bf16 storage exists on the direct kernels only
   MO_CHECK_ARG(!stats);                          // (mo_conv3x3_stats_tiles() == 0 for every shape that gets here ...
   MoOperand A = uplain(W, Ci * 9, Co, Ci * 9);   // XROWS: rows = m = co, cols = k = (ci,tap)
   MoOperand B = im2col_operand(in0, C0, istride0, sc0, sh0, relu0, in1, C1, istride1, sc1, sh1, relu1, P);
@@ -201,7 +209,7 @@ extern "C" int mo_conv3x3_flip_weights(const float* W, int Co, int Ci, float* Wf
 extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, const float* in0, int C0, long istride0,
                                      const float* sc0, const float* sh0, int relu0, const float* in1, int C1,
                                      long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
-                                     long n_img, int H, int Wd, float* dW, float* ws, void* stream) {
+                                     long n_img, int H, int Wd, float* dW, float* ws, int dtypes, void* stream) {
   MO_CHECK_ARG(dy && in0 && dW && ws && C0 > 0 && C1 >= 0 && Co > 0 && n_img > 0 && (Wd % 4) == 0);
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31));
@@ -222,6 +230,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
       a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
       a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UW_CIC);
+      a.bfd = (dtypes & MO_BF_DY) != 0; a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0;
       dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)a.n_cichunk);
       hipStream_t st = ST(stream);
       const int cmax = Ci < UW_CIC ? Ci : UW_CIC;
@@ -237,6 +246,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       return mo_launch_status();
     }
   }
+  if (dtypes) return MO_EUNSUPPORTED;            // bf16 storage: the MFMA weight-gradient kernel above only
   if (Co <= 32 && (long)Co * Ci <= 128 && H >= 32 && Wd >= 32 && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0) {
     // thin layers (Co*Ci <= 128, measured crossover: beyond it the 4x2-channel blocking re-reads dy / the halo too
     // often and the split-K implicit GEMM wins): direct weight gradient on LDS spatial tiles (unet_direct.hpp)
@@ -253,6 +263,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
       a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
       a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UD_WI);
+      a.bfd = a.bf0 = a.bf1 = 0;
       dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)(a.n_cichunk * mo_cdiv(Co, UD_WC)));
       hipStream_t st = ST(stream);
       if (wide) hipLaunchKernelGGL((ud_wgrad3x3_kernel<16, 64>), grid, dim3(256), 0, st, a);
@@ -288,15 +299,17 @@ static int ut_launch(const UtArgs& a, hipStream_t st) {
 }
 extern "C" int mo_nchw_conv1x1_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                                    int gsize, const float* W, const float* b, int Co, long n_img, int HW, float* out,
-                                   long ostride, void* stream) {
+                                   long ostride, int dtypes, void* stream) {
   MO_CHECK_ARG(in && W && out && Ci > 0 && Co > 0 && n_img > 0 && HW > 0 && (HW % 4) == 0);
   const long P = n_img * HW;
   MO_CHECK_ARG(P < (1L << 31));
   if (ut_ok(in, istride, out, ostride, Ci, Co, n_img)) {
     UtArgs a; a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize;
     a.W = W; a.b = b; a.out = out; a.os = ostride; a.Co = Co; a.n_img = n_img; a.HW = HW;
+    a.bfi = (dtypes & MO_BF_IN0) != 0; a.bfo = (dtypes & MO_BF_OUT) != 0;
     return ut_launch<false>(a, ST(stream));
   }
+  if (dtypes) return MO_EUNSUPPORTED;
   MoOperand A = uplain(W, Ci, Co, Ci);                                            // XROWS rows = co, cols = ci
   MoOperand B; uop(B, Ci, P); useg(B.seg[0], in, istride, sc, sh, relu);           // NCHW KROWS rows = ci, cols = p
   MoEpi E; uepi(E, out, ostride); E.bias = b;
@@ -304,14 +317,16 @@ extern "C" int mo_nchw_conv1x1_fwd(const float* in, long istride, int Ci, const 
   return ulaunch_fwd<MO_XROWS, MO_EPI_NCHW, MO_SRC_PLAIN, MO_SRC_NCHW>(A, B, E, G, Co, P, ST(stream));
 }
 extern "C" int mo_nchw_conv1x1_bwd_data(const float* dout, long dostride, int Co, const float* W, int Ci, long n_img,
-                                        int HW, float* din, long distride, void* stream) {
+                                        int HW, float* din, long distride, int dtypes, void* stream) {
   MO_CHECK_ARG(dout && W && din && Ci > 0 && Co > 0 && n_img > 0 && (HW % 4) == 0);
   const long P = n_img * HW;
   if (ut_ok(dout, dostride, din, distride, Co, Ci, n_img)) {
     UtArgs a; a.in = dout; a.is = dostride; a.Ci = Co; a.sc = nullptr; a.sh = nullptr; a.relu = 0; a.gsize = 1;
     a.W = W; a.b = nullptr; a.out = din; a.os = distride; a.Co = Ci; a.n_img = n_img; a.HW = HW;
+    a.bfi = (dtypes & MO_BF_DY) != 0; a.bfo = (dtypes & MO_BF_OUT) != 0;
     return ut_launch<true>(a, ST(stream));
   }
+  if (dtypes) return MO_EUNSUPPORTED;
   MoOperand A = uplain(W, Ci, Co, Ci);                                            // KROWS rows = k = co, cols = m = ci
   MoOperand B; uop(B, Co, P); useg(B.seg[0], dout, dostride, nullptr, nullptr, 0);  // NCHW KROWS rows = co
   MoEpi E; uepi(E, din, distride);
@@ -322,7 +337,7 @@ extern "C" int mo_nchw_channel_sum(const float* x, long istride, int C, long n_i
                                    void* stream);
 extern "C" int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride,
                                           int Ci, const float* sc, const float* sh, int relu, int gsize, long n_img,
-                                          int HW, float* dW, float* db, float* ws, void* stream) {
+                                          int HW, float* dW, float* db, float* ws, int dtypes, void* stream) {
   MO_CHECK_ARG(dout && in && dW && ws && Ci > 0 && Co > 0 && n_img > 0 && (HW % 4) == 0);
   const long P = n_img * HW;
   const bool t44 = Ci <= 4 && Co <= 16, t88 = Ci <= 8 && Co <= 8, t416 = Ci <= 16 && Co <= 4;
@@ -334,6 +349,7 @@ extern "C" int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int 
     UtWgArgs a; a.dout = dout; a.dos = dostride; a.Co = Co; a.in = in; a.is = istride; a.Ci = Ci;
     a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize; a.slab = ws; a.n_img = n_img; a.HW = HW;
     a.img_per_wg = (int)ipw;
+    a.bfd = (dtypes & MO_BF_DY) != 0; a.bfi = (dtypes & MO_BF_IN0) != 0;
     dim3 grid(gx, (unsigned)gy);
     hipStream_t st = ST(stream);
     if (t44) {
@@ -348,6 +364,7 @@ extern "C" int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int 
     if (db) hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(Co, 32)), dim3(1024), 0, st, ws + nw, nrow, nz, db, (long)Co);
     return mo_launch_status();
   }
+  if (dtypes) return MO_EUNSUPPORTED;
   if (db) {       // bias gradient of the general path: per-channel sum of dout (workspace: the head of ws, reused below)
     int rc = mo_nchw_channel_sum(dout, dostride, Co, n_img, HW, db, ws, stream);
     if (rc) return rc;
@@ -494,7 +511,8 @@ extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int g
 // activation materialise (+ optional 2x2 max-pool, unet.py:60): out = pool?(relu(y*sc+sh))
 // ------------------------------------------------------------------------------------------------
 __global__ void unet_act_kernel(const float* __restrict__ y, long istride, int C, int H, int W, const float* sc,
-                                const float* sh, int gsize, int pool, float* __restrict__ out, long ostride, long total) {
+                                const float* sh, int gsize, int pool, float* __restrict__ out, long ostride, long total,
+                                int bfi, int bfo) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
@@ -503,26 +521,29 @@ __global__ void unet_act_kernel(const float* __restrict__ y, long istride, int C
   const int c = (int)(r % C); const long img = r / C;
   float s = 1.f, t = 0.f;
   if (sc) { const long g = img / gsize; s = sc[g * C + c]; t = sh[g * C + c]; }
-  const float* p = y + img * istride + (long)c * H * W;
+  const long p = img * istride + (long)c * H * W;
   float v;
   if (pool) {
-    const float* q = p + (long)(2 * yy) * W + 2 * x;
-    float a = q[0] * s + t, b = q[1] * s + t, cc = q[W] * s + t, d = q[W + 1] * s + t;
+    const long q = p + (long)(2 * yy) * W + 2 * x;
+    float a = ua_ld1(y, q, bfi) * s + t, b = ua_ld1(y, q + 1, bfi) * s + t, cc = ua_ld1(y, q + W, bfi) * s + t,
+          d = ua_ld1(y, q + W + 1, bfi) * s + t;
     v = fmaxf(fmaxf(a, b), fmaxf(cc, d));
   } else {
-    v = p[(long)yy * W + x] * s + t;
+    v = ua_ld1(y, p + (long)yy * W + x, bfi) * s + t;
   }
   if (sc) v = fmaxf(v, 0.f);
-  out[img * ostride + ((long)c * Ho + yy) * Wo + x] = v;
+  const long o = img * ostride + ((long)c * Ho + yy) * Wo + x;
+  if (bfo) { __bf16 tb = (__bf16)v; reinterpret_cast<unsigned short*>(out)[o] = __builtin_bit_cast(unsigned short, tb); }
+  else out[o] = v;
 }
 extern "C" int mo_unet_act(const float* y, long istride, int C, long n_img, int H, int Wd, const float* sc,
-                           const float* sh, int gsize, int pool, float* out, long ostride, void* stream) {
+                           const float* sh, int gsize, int pool, float* out, long ostride, int dtypes, void* stream) {
   MO_CHECK_ARG(y && out && C > 0 && n_img > 0 && H > 0 && Wd > 0 && gsize > 0);
   MO_CHECK_ARG((sc == nullptr) == (sh == nullptr));
   MO_CHECK_ARG(!pool || ((H % 2) == 0 && (Wd % 2) == 0));
   long total = n_img * C * (pool ? (H / 2) * (Wd / 2) : H * Wd);
   hipLaunchKernelGGL(unet_act_kernel, dim3(mo_cdiv(total, 256)), dim3(256), 0, ST(stream), y, istride, C, H, Wd, sc, sh,
-                     gsize, pool, out, ostride, total);
+                     gsize, pool, out, ostride, total, (dtypes & MO_BF_IN0) != 0, (dtypes & MO_BF_OUT) != 0);
   return mo_launch_status();
 }
 
@@ -580,20 +601,24 @@ __device__ __forceinline__ float unet_dz(const float* __restrict__ yp, int H, in
 }
 // dz of the 4 pixels (yy, 4q..4q+3) of one channel plane: 16-byte loads; with max-pool routing the partner row of the
 // 2x2 windows is read as well (the first maximum in scan order takes the pooled gradient, as F.max_pool2d does)
-__device__ __forceinline__ void unet_dz4(const float* __restrict__ yp, int W, int yy, int q, float s, float t,
-                                         const float* __restrict__ da_p, const float* __restrict__ dp_p, float4& yv,
-                                         float (&dz)[4]) {
-  yv = *reinterpret_cast<const float4*>(yp + (long)yy * W + 4 * q);
+struct UaFlags { int y, da, dp, dy; };       // bf16 storage of the four tensors of the activation backward
+__device__ __forceinline__ void unet_dz4(const float* __restrict__ ybase, long yoff, int W, int yy, int q, float s, float t,
+                                         const float* __restrict__ da_base, long daoff, const float* __restrict__ dp_base,
+                                         long dpoff, UaFlags f, float4& yv, float (&dz)[4]) {
+  yv = ua_ld4(ybase, yoff + (long)yy * W + 4 * q, f.y);
   const float a[4] = {yv.x * s + t, yv.y * s + t, yv.z * s + t, yv.w * s + t};
   float d[4] = {0.f, 0.f, 0.f, 0.f};
-  if (da_p) {
-    const float4 v = *reinterpret_cast<const float4*>(da_p + (long)yy * W + 4 * q);
+  if (da_base) {
+    const float4 v = ua_ld4(da_base, daoff + (long)yy * W + 4 * q, f.da);
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
-  if (dp_p) {
-    const float4 ov = *reinterpret_cast<const float4*>(yp + (long)(yy ^ 1) * W + 4 * q);
+  if (dp_base) {
+    const float4 ov = ua_ld4(ybase, yoff + (long)(yy ^ 1) * W + 4 * q, f.y);
     const float o[4] = {ov.x * s + t, ov.y * s + t, ov.z * s + t, ov.w * s + t};
-    const float2 g = *reinterpret_cast<const float2*>(dp_p + (long)(yy >> 1) * (W >> 1) + 2 * q);
+    float2 g;
+    const long gi = dpoff + (long)(yy >> 1) * (W >> 1) + 2 * q;
+    if (f.dp) { const unsigned u = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(dp_base) + gi); g = make_float2(ua_lo(u), ua_hi(u)); }
+    else g = *reinterpret_cast<const float2*>(dp_base + gi);
     const bool top = (yy & 1) == 0;
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
@@ -617,7 +642,7 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                             const float* __restrict__ sc, const float* __restrict__ sh,
                                             const float* __restrict__ da, long dastride, const float* __restrict__ dp,
-                                            long dpstride, double* __restrict__ part) {
+                                            long dpstride, double* __restrict__ part, UaFlags f) {
   // The two sums feed mean subtractions whose error is multiplied by sum(x) in the weight gradients downstream (x >= 0
   // after ReLU, so that factor does not cancel): thread-private partial sums in fp32 over at most 64 quads, everything
   // above that in double (torch's CPU BatchNorm backward accumulates in double too).
@@ -625,15 +650,14 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
   const int c = blockIdx.x; const long img = blockIdx.y;
   const long g = img / gsize;
   const float s = sc[g * C + c], t = sh[g * C + c], mu = mean[g * C + c], rs = rstd[g * C + c];
-  const float* yp = y + img * istride + (long)c * H * W;
-  const float* dap = da ? da + img * dastride + (long)c * H * W : nullptr;
-  const float* dpp = dp ? dp + img * dpstride + (long)c * (H / 2) * (W / 2) : nullptr;
+  const long yoff = img * istride + (long)c * H * W, daoff = img * dastride + (long)c * H * W;
+  const long dpoff = img * dpstride + (long)c * (H / 2) * (W / 2);
   const int Q = W >> 2;
   double s1 = 0.0, s2 = 0.0;
   for (int i = threadIdx.x; i < H * Q; i += blockDim.x) {
     const int yy = i / Q, q = i - yy * Q;
     float4 yv; float dz[4];
-    unet_dz4(yp, W, yy, q, s, t, dap, dpp, yv, dz);
+    unet_dz4(y, yoff, W, yy, q, s, t, da, daoff, dp, dpoff, f, yv, dz);
     const float xh[4] = {(yv.x - mu) * rs, (yv.y - mu) * rs, (yv.z - mu) * rs, (yv.w - mu) * rs};
     s1 += (double)((dz[0] + dz[1]) + (dz[2] + dz[3]));
     s2 += (double)dz[0] * xh[0] + (double)dz[1] * xh[1] + (double)dz[2] * xh[2] + (double)dz[3] * xh[3];
@@ -674,7 +698,7 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
                                           const float* __restrict__ rstd, const float* __restrict__ sc,
                                           const float* __restrict__ sh, const float* __restrict__ da, long dastride,
                                           const float* __restrict__ dp, long dpstride, const double* __restrict__ k12,
-                                          float* __restrict__ dy, long dystride, long total4) {
+                                          float* __restrict__ dy, long dystride, long total4, UaFlags f) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int Q = W >> 2;
@@ -683,11 +707,10 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   const int c = (int)(r % C); const long img = r / C;
   const long g = img / gsize;
   const float s = sc[g * C + c], t = sh[g * C + c], mu = mean[g * C + c], rs = rstd[g * C + c];
-  const float* yp = y + img * istride + (long)c * H * W;
-  const float* dap = da ? da + img * dastride + (long)c * H * W : nullptr;
-  const float* dpp = dp ? dp + img * dpstride + (long)c * (H / 2) * (W / 2) : nullptr;
+  const long yoff = img * istride + (long)c * H * W, daoff = img * dastride + (long)c * H * W;
+  const long dpoff = img * dpstride + (long)c * (H / 2) * (W / 2);
   float4 yv; float dz[4];
-  unet_dz4(yp, W, yy, q, s, t, dap, dpp, yv, dz);
+  unet_dz4(y, yoff, W, yy, q, s, t, da, daoff, dp, dpoff, f, yv, dz);
   // the two group means are subtracted in double: rounded to fp32 their error would be the same for every pixel of
   // the group and come back multiplied by sum(x) in the weight gradient (measured 8e-4 of a gradient's scale)
   const double k1 = k12[(g * C + c) * 2], k2 = k12[(g * C + c) * 2 + 1];
@@ -697,13 +720,14 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   o.y = gr * (float)((double)dz[1] - k1 - (double)((yv.y - mu) * rs) * k2);
   o.z = gr * (float)((double)dz[2] - k1 - (double)((yv.z - mu) * rs) * k2);
   o.w = gr * (float)((double)dz[3] - k1 - (double)((yv.w - mu) * rs) * k2);
-  *reinterpret_cast<float4*>(dy + img * dystride + ((long)c * H + yy) * W + 4 * q) = o;
+  ua_st4(dy, img * dystride + ((long)c * H + yy) * W + 4 * q, o, f.dy);
 }
 extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * 8 + 64; }   // double partials + double k12
 extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
                                const float* gamma, const float* mean, const float* rstd, const float* sc,
                                const float* sh, const float* da, long dastride, const float* dp, long dpstride,
-                               float* dy, long dystride, float* dgamma, float* dbeta, float* ws, void* stream) {
+                               float* dy, long dystride, float* dgamma, float* dbeta, float* ws, int dtypes,
+                               void* stream) {
   MO_CHECK_ARG(y && gamma && mean && rstd && sc && sh && dy && dgamma && dbeta && ws && (da || dp));
   MO_CHECK_ARG(C > 0 && n_img > 0 && n_img <= 65535 && gsize > 0 && (n_img % gsize) == 0);
   MO_CHECK_ARG(!dp || ((H % 2) == 0 && (Wd % 2) == 0));
@@ -711,18 +735,19 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
                (dystride & 3) == 0 && (!da || ((((uintptr_t)da) & 15) == 0 && (dastride & 3) == 0)) &&
                (!dp || ((((uintptr_t)dp) & 7) == 0 && (dpstride & 1) == 0)));
   hipStream_t st = ST(stream);
+  const UaFlags fl = {(dtypes & MO_BF_IN0) != 0, (dtypes & MO_BF_IN1) != 0, (dtypes & MO_BF_DP) != 0, (dtypes & MO_BF_OUT) != 0};
   MO_CHECK_ARG((((uintptr_t)ws) & 7) == 0);
   double* part = reinterpret_cast<double*>(ws);
   double* k12 = part + n_img * C * 2;
   const int HW = H * Wd;
   hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img), dim3(HW >= 1024 ? 256 : 64), 0, st, y, istride,
-                     C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part);
+                     C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part, fl);
   const long G = n_img / gsize;
   hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, k12);
   hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
   const long total4 = n_img * C * (HW / 4);
   hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total4, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
-                     gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4);
+                     gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4, fl);
   return mo_launch_status();
 }
 

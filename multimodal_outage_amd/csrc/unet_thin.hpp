@@ -4,6 +4,7 @@
 // 2.5 ms of a 24 ms config-3 step on them.  A thread owns 4 neighbouring pixels (one 16-byte piece per plane).
 #pragma once
 #include "mo_common.h"
+#include "unet_direct.hpp"     // ua_ld4 / ua_st4: fp32 or bf16 activation storage
 
 struct UtArgs {
   const float* in; long is; int Ci;
@@ -11,6 +12,7 @@ struct UtArgs {
   const float* W;  const float* b;                      // (Co, Ci) row-major; transposed use: see kernels
   float* out; long os; int Co;
   long n_img; int HW;
+  int bfi, bfo;                                          // storage of in / out: 0 fp32, 1 bf16
 };
 
 // out[img][co][p] = b[co] + sum_ci Wm[co][ci] * act(in[img][ci][p]);  TRANS: Wm[co][ci] = W[ci][co] (data gradient of
@@ -30,14 +32,12 @@ __global__ __launch_bounds__(256) void ut_conv1x1_kernel(UtArgs a) {
   __syncthreads();
   const long img = blockIdx.y;
   const long grp = img / a.gsize;
-  const float* ip = a.in + img * a.is;
-  float* op = a.out + img * a.os;
   for (int p = (blockIdx.x * 256 + tid) * 4; p < a.HW; p += gridDim.x * 1024) {
     float4 acc[CO];
 #pragma unroll
     for (int co = 0; co < CO; ++co) { const float b = bsm[co]; acc[co] = make_float4(b, b, b, b); }
     for (int ci = 0; ci < a.Ci; ++ci) {
-      float4 v = *reinterpret_cast<const float4*>(ip + (long)ci * a.HW + p);
+      float4 v = ua_ld4(a.in, img * a.is + (long)ci * a.HW + p, a.bfi);
       if (a.sc) {
         const float s = a.sc[grp * a.Ci + ci], t = a.sh[grp * a.Ci + ci];
         v.x = v.x * s + t; v.y = v.y * s + t; v.z = v.z * s + t; v.w = v.w * s + t;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void ut_conv1x1_kernel(UtArgs a) {
     }
 #pragma unroll
     for (int co = 0; co < CO; ++co)
-      if (co < a.Co) *reinterpret_cast<float4*>(op + (long)co * a.HW + p) = acc[co];
+      if (co < a.Co) ua_st4(a.out, img * a.os + (long)co * a.HW + p, acc[co], a.bfo);
   }
 }
 
@@ -64,6 +64,7 @@ struct UtWgArgs {
   const float* sc; const float* sh; int relu, gsize;
   float* slab;            // [gridDim.y * gridDim.x][Co*Ci + Co]
   long n_img; int HW, img_per_wg;
+  int bfd, bfi;           // storage of dout / in
 };
 template <int CO, int CI>
 __global__ __launch_bounds__(256) void ut_wgrad1x1_kernel(UtWgArgs a) {
@@ -79,15 +80,13 @@ __global__ __launch_bounds__(256) void ut_wgrad1x1_kernel(UtWgArgs a) {
   const long img0 = (long)blockIdx.y * a.img_per_wg, img1 = min(img0 + a.img_per_wg, a.n_img);
   for (long img = img0; img < img1; ++img) {
     const long grp = img / a.gsize;
-    const float* dp = a.dout + img * a.dos;
-    const float* ip = a.in + img * a.is;
     for (int p = (blockIdx.x * 256 + tid) * 4; p < a.HW; p += gridDim.x * 1024) {
       float4 x[CI];
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ci < a.Ci) {
-          v = *reinterpret_cast<const float4*>(ip + (long)ci * a.HW + p);
+          v = ua_ld4(a.in, img * a.is + (long)ci * a.HW + p, a.bfi);
           if (a.sc) {
             const float s = a.sc[grp * a.Ci + ci], t = a.sh[grp * a.Ci + ci];
             v.x = v.x * s + t; v.y = v.y * s + t; v.z = v.z * s + t; v.w = v.w * s + t;
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256) void ut_wgrad1x1_kernel(UtWgArgs a) {
 #pragma unroll
       for (int co = 0; co < CO; ++co) {
         if (co < a.Co) {
-          const float4 d = *reinterpret_cast<const float4*>(dp + (long)co * a.HW + p);
+          const float4 d = ua_ld4(a.dout, img * a.dos + (long)co * a.HW + p, a.bfd);
           accb[co] += (d.x + d.y) + (d.z + d.w);
 #pragma unroll
           for (int ci = 0; ci < CI; ++ci) acc[co][ci] += d.x * x[ci].x + d.y * x[ci].y + d.z * x[ci].z + d.w * x[ci].w;

@@ -175,6 +175,9 @@ class Modified_UNET(nn.Module):
             print(f'Please select a valid spatiotemporal graph neural network.')
         self.decoder = Decoder(self.horizon) if image_dimension == 128 else Decoder(self.horizon, image_dimension)
         self.expansion = Expansion(output_channels)
+        # 'f32' (parity mode) | 'bf16' (BASELINE config 3): the raw conv outputs and their gradients at the large
+        # resolutions are stored as bf16 in HBM, arithmetic stays fp32 (unet_engine.bf_ok)
+        self.act_dtype = 'f32'
 
     # ------------------------------------------------------------------ engine plumbing
     def _names(self, prefixes):
@@ -200,7 +203,8 @@ class Modified_UNET(nn.Module):
         # Graph-WaveNet inside is called once per batch element (unet.py:221), so its gradients must accumulate
         # through autograd and are not registered here.
         state = dict(gsize=H, training=self.training, bufs=self._bufs(),
-                     fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None))
+                     fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None),
+                     act_dtype=getattr(self, 'act_dtype', 'f32'))
         enc_names = self._names(('contraction', 'encoder'))
         dec_names = self._names(('decoder', 'expansion'))
         st_e = dict(state, names=enc_names)

@@ -26,7 +26,7 @@ def _materialise(v, n, gs, pool=0):
     Ho, Wo = (v.H // 2, v.W // 2) if pool else (v.H, v.W)
     out = _empty(n, v.C, Ho, Wo, dev=v.t.device)
     L.call('mo_unet_act', L.ptr(v.t), v.istride, v.C, n, v.H, v.W, L.ptr(v.sc), L.ptr(v.sh), gs, pool, L.ptr(out),
-           v.C * Ho * Wo, L.stream())
+           v.C * Ho * Wo, L.BF_IN0 * v.bf, L.stream())
     return out
 
 
@@ -133,7 +133,7 @@ class OutConvFn(torch.autograd.Function):
         Co = W.shape[0]
         out = _empty(n, Co, H, Wd, dev=x.device)
         L.call('mo_nchw_conv1x1_fwd', L.ptr(x), Ci * H * Wd, Ci, None, None, 0, 1, L.ptr(W), L.ptr(b), Co, n, H * Wd,
-               L.ptr(out), Co * H * Wd, L.stream())
+               L.ptr(out), Co * H * Wd, 0, L.stream())
         ctx.save_for_backward(x, W)
         return out
 
@@ -149,9 +149,9 @@ class OutConvFn(torch.autograd.Function):
         db = _empty(Co, dev=dev)
         ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Co, Ci, n * HW), n * Co * 2), device=dev, dtype=torch.float32)
         L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Co * HW, Co, L.ptr(x), Ci * HW, Ci, None, None, 0, 1, n, HW,
-               L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+               L.ptr(dW), L.ptr(db), L.ptr(ws), 0, L.stream())
         dx = _empty(n, Ci, H, Wd, dev=dev)
-        L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Co * HW, Co, L.ptr(W), Ci, n, HW, L.ptr(dx), Ci * HW, L.stream())
+        L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Co * HW, Co, L.ptr(W), Ci, n, HW, L.ptr(dx), Ci * HW, 0, L.stream())
         return None, dx, dW, db
 
 
@@ -248,7 +248,7 @@ class ExpansionFn(torch.autograd.Function):
         Cout = Wo.shape[0]
         out = _empty(n, Cout, v.H, v.W, dev=dev)
         L.call('mo_nchw_conv1x1_fwd', L.ptr(v.t), v.istride, v.C, L.ptr(v.sc), L.ptr(v.sh), 1, gs, L.ptr(Wo), L.ptr(bo),
-               Cout, n, v.H * v.W, L.ptr(out), Cout * v.H * v.W, st)
+               Cout, n, v.H * v.W, L.ptr(out), Cout * v.H * v.W, 0, st)
         ctx.cfg, ctx.p, ctx.ups, ctx.vlast, ctx.n = cfg, p, ups, v, n
         return out
 
@@ -268,9 +268,9 @@ class ExpansionFn(torch.autograd.Function):
         dbo = grads.buf('outc.conv.bias', (Cout,))
         ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), n * Cout * 2), device=dev, dtype=torch.float32)
         L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Cout * HW, Cout, L.ptr(v.t), v.istride, C4, L.ptr(v.sc),
-               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), st)
+               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), 0, st)
         da = _empty(n, C4, v.H, v.W, dev=dev)
-        L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW, st)
+        L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW, 0, st)
         dfm = [None] * 4
         for k in (4, 3, 2, 1):
             up = ctx.ups[k - 1]

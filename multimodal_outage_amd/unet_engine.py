@@ -25,6 +25,11 @@ class View:
     def istride(self):
         return self.C * self.H * self.W
 
+    @property
+    def bf(self):
+        """1 when the tensor is stored as bf16 ("bf16 mode": raw conv outputs and gradients at the large resolutions)."""
+        return int(self.t.dtype == torch.bfloat16)
+
     def args(self):
         return (L.ptr(self.t), self.C, self.istride, L.ptr(self.sc), L.ptr(self.sh), 1 if self.sc is not None else 0)
 
@@ -32,8 +37,19 @@ class View:
 _NOVIEW = (None, 0, 0, None, None, 0)
 
 
-def _empty(*shape, dev):
-    return torch.empty(shape, device=dev, dtype=torch.float32)
+def _empty(*shape, dev, bf=False):
+    return torch.empty(shape, device=dev, dtype=torch.bfloat16 if bf else torch.float32)
+
+
+def bf_ok(mode, Co, H, W):
+    """bf16 storage of an activation tensor of Co channels at H x W: only where every kernel that touches it is a direct /
+    streaming one (include/mo_hip.h `dtypes`): the MFMA weight gradient needs W % 64 == 0 and H % 8 == 0, the direct
+    conv <= 32 output channels."""
+    return bool(mode == 'bf16' and Co <= 32 and H % 8 == 0 and W % 64 == 0 and H >= 64)
+
+
+def _is_bf(t):
+    return int(t is not None and t.dtype == torch.bfloat16)
 
 
 class Grads(dict):
@@ -55,17 +71,18 @@ class Grads(dict):
         return tuple(None if (k in self.gout and self.gout[k] is not None) else self.get(k) for k in names)
 
 
-def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev):
+def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev, out_bf=False):
     v0 = views[0]
     H, W = v0.H, v0.W
     st = L.stream()
-    y = _empty(n, Co, H, W, dev=dev)
+    y = _empty(n, Co, H, W, dev=dev, bf=out_bf)
     a1 = views[1].args() if len(views) > 1 else _NOVIEW
+    dt = (L.BF_IN0 * v0.bf) | (L.BF_IN1 * (views[1].bf if len(views) > 1 else 0)) | (L.BF_OUT * int(out_bf))
     # train mode: the BatchNorm statistics come out of the conv's own epilogue where the direct kernels run
     # (per-tile partial sums), else from one pass over the output
     ntile = L.load().mo_conv3x3_stats_tiles(Co, n, H, W) if training else 0
     stats = _empty(n, ntile, Co, 2, dev=dev) if ntile else None
-    L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, L.ptr(stats), st)
+    L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, L.ptr(stats), dt, st)
     G = n // gs
     aff = _empty(4, G, Co, dev=dev)            # scale, shift, mean, rstd
     if training and not ntile:
@@ -80,12 +97,14 @@ def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev):
     return y, aff
 
 
-def double_conv_fwd(p, pre, views, Co, n, gs, training, bufs, dev):
-    """unet.py:40-53.  Returns (saved, output view)."""
+def double_conv_fwd(p, pre, views, Co, n, gs, training, bufs, dev, bf=(False, False)):
+    """unet.py:40-53.  Returns (saved, output view).  bf = (y1, y2 stored as bf16)."""
     H, W = views[0].H, views[0].W
-    y1, aff1 = _conv_bn(p, pre + '.double_conv.0.weight', pre + '.double_conv.1', views, Co, n, gs, training, bufs, dev)
+    y1, aff1 = _conv_bn(p, pre + '.double_conv.0.weight', pre + '.double_conv.1', views, Co, n, gs, training, bufs, dev,
+                        bf[0])
     v1 = View(y1, Co, H, W, aff1[0], aff1[1])
-    y2, aff2 = _conv_bn(p, pre + '.double_conv.3.weight', pre + '.double_conv.4', [v1], Co, n, gs, training, bufs, dev)
+    y2, aff2 = _conv_bn(p, pre + '.double_conv.3.weight', pre + '.double_conv.4', [v1], Co, n, gs, training, bufs, dev,
+                        bf[1])
     v2 = View(y2, Co, H, W, aff2[0], aff2[1])
     return dict(pre=pre, views=views, y1=y1, aff1=aff1, v1=v1, y2=y2, aff2=aff2, Co=Co, H=H, W=W), v2
 
@@ -106,7 +125,7 @@ def _dastride(t):
     return t, t.stride(0)
 
 
-def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=True):
+def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=True, dx_bf=False):
     """Backward of DoubleConv.  da: gradient w.r.t. the activated output view (may be a channel slice of
     a wider buffer), dp: gradient w.r.t. its 2x2 max-pooled version.  Returns the gradient w.r.t. the
     (activated) channel-concatenated input, shape (n, C0+C1, H, W), or None."""
@@ -116,14 +135,15 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
     HW = H * W
 
     def act_bwd(y, aff, bnkey, da_t, dp_t):
-        dy = _empty(n, Co, H, W, dev=dev)
+        dy = _empty(n, Co, H, W, dev=dev, bf=_is_bf(y))          # the gradient of a conv output is stored as the output is
         dg = grads.buf(bnkey + '.weight', (Co,))
         db = grads.buf(bnkey + '.bias', (Co,))
         ws = torch.empty(lib.mo_unet_act_bwd_ws_floats(n, Co), device=dev, dtype=torch.float32)
         da_t, das = _dastride(da_t)
         L.call('mo_unet_act_bwd', L.ptr(y), Co * HW, Co, n, H, W, gs, L.ptr(p[bnkey + '.weight']), L.ptr(aff[2]),
                L.ptr(aff[3]), L.ptr(aff[0]), L.ptr(aff[1]), da_t.data_ptr() if da_t is not None else None, das,
-               L.ptr(dp_t), (Co * HW) // 4, L.ptr(dy), Co * HW, L.ptr(dg), L.ptr(db), L.ptr(ws), st)
+               L.ptr(dp_t), (Co * HW) // 4, L.ptr(dy), Co * HW, L.ptr(dg), L.ptr(db), L.ptr(ws),
+               (L.BF_IN0 * _is_bf(y)) | (L.BF_IN1 * _is_bf(da_t)) | (L.BF_DP * _is_bf(dp_t)) | (L.BF_OUT * _is_bf(dy)), st)
         return dy
 
     def wgrad(dy, views, wkey):
@@ -131,25 +151,26 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
         dW = grads.buf(wkey, (Co, Ci, 3, 3))
         ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * HW), device=dev, dtype=torch.float32)
         a1 = views[1].args() if len(views) > 1 else _NOVIEW
+        dt = (L.BF_DY * _is_bf(dy)) | (L.BF_IN0 * views[0].bf) | (L.BF_IN1 * (views[1].bf if len(views) > 1 else 0))
         L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * HW, Co, *views[0].args(), *a1, gs, n, H, W, L.ptr(dW),
-               L.ptr(ws), st)
+               L.ptr(ws), dt, st)
 
-    def dgrad(dy, Wt):
+    def dgrad(dy, Wt, out_bf):
         Ci = Wt.shape[1]
         Wf = _flip(Wt, dev)
-        dx = _empty(n, Ci, H, W, dev=dev)
+        dx = _empty(n, Ci, H, W, dev=dev, bf=out_bf)
         L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wf), Ci, n, H, W,
-               L.ptr(dx), Ci * HW, None, st)
+               L.ptr(dx), Ci * HW, None, (L.BF_IN0 * _is_bf(dy)) | (L.BF_OUT * int(out_bf)), st)
         return dx
 
     dy2 = act_bwd(sv['y2'], sv['aff2'], pre + '.double_conv.4', da, dp)
     wgrad(dy2, [sv['v1']], pre + '.double_conv.3.weight')
-    da1 = dgrad(dy2, p[pre + '.double_conv.3.weight'])
+    da1 = dgrad(dy2, p[pre + '.double_conv.3.weight'], _is_bf(sv['y1']))      # consumed by y1's activation backward
     dy1 = act_bwd(sv['y1'], sv['aff1'], pre + '.double_conv.1', da1, None)
     wgrad(dy1, sv['views'], pre + '.double_conv.0.weight')
     if not need_input_grad:
         return None
-    return dgrad(dy1, p[pre + '.double_conv.0.weight'])
+    return dgrad(dy1, p[pre + '.double_conv.0.weight'], dx_bf)
 
 
 def _fc_fwd(x, W, b, relu):
@@ -236,22 +257,25 @@ class UnetEncodeFn(torch.autograd.Function):
         x = x.contiguous()
         st = L.stream()
         saved = []
-        sv, v = double_conv_fwd(p, 'contraction.inc', [View(x, Cin, S, S)], 4, n, gs, training, bufs, dev)
+        mode = state.get('act_dtype', 'f32')      # 'bf16': conv outputs / gradients of the large levels stored as bf16
+        b0 = bf_ok(mode, 4, S, S)
+        sv, v = double_conv_fwd(p, 'contraction.inc', [View(x, Cin, S, S)], 4, n, gs, training, bufs, dev, bf=(b0, b0))
         saved.append(sv)
         views = [v]
         for k, (ci, co) in enumerate(ENC_CH, 1):
             H = v.H
-            pooled = _empty(n, ci, H // 2, H // 2, dev=dev)
+            bk = bf_ok(mode, co, H // 2, H // 2)
+            pooled = _empty(n, ci, H // 2, H // 2, dev=dev, bf=bk)
             L.call('mo_unet_act', L.ptr(v.t), v.istride, ci, n, H, H, L.ptr(v.sc), L.ptr(v.sh), gs, 1, L.ptr(pooled),
-                   ci * (H // 2) * (H // 2), st)
+                   ci * (H // 2) * (H // 2), (L.BF_IN0 * v.bf) | (L.BF_OUT * int(bk)), st)
             sv, v = double_conv_fwd(p, f'contraction.down{k}.maxpool_conv.1', [View(pooled, ci, H // 2, H // 2)], co, n,
-                                    gs, training, bufs, dev)
+                                    gs, training, bufs, dev, bf=(bk, bk))
             saved.append(sv)
             views.append(v)
         v5 = views[-1]
         x5a = _empty(n, v5.C, v5.H, v5.W, dev=dev)
         L.call('mo_unet_act', L.ptr(v5.t), v5.istride, v5.C, n, v5.H, v5.W, L.ptr(v5.sc), L.ptr(v5.sh), gs, 0, L.ptr(x5a),
-               v5.istride, st)
+               v5.istride, L.BF_IN0 * v5.bf, st)
         fc_sv, feat = fc_block_fwd(p, 'encoder', x5a.view(n, -1), _drop_params(state['fc_dropout'], training))
         # the decoder needs the skip maps' folded BatchNorm affine; the maps themselves reach it as Function inputs
         state['skip_meta'] = [(v.C, v.H, v.W, v.sc, v.sh) for v in views[:4]]
@@ -279,11 +303,14 @@ class UnetEncodeFn(torch.autograd.Function):
         saved = [dict(sv, y2=outs[1 + k]) if k < 4 else sv for k, sv in enumerate(saved)]
         dx5a = fc_block_bwd(p, fc_sv, dfeat, grads)
         v5 = saved[4]
-        dp = double_conv_bwd(p, saved[4], n, gs, grads, dev, da=dx5a.view(n, v5['Co'], v5['H'], v5['W']), dp=None)
+        dp = double_conv_bwd(p, saved[4], n, gs, grads, dev, da=dx5a.view(n, v5['Co'], v5['H'], v5['W']), dp=None,
+                             dx_bf=bool(saved[4]['views'][0].bf))
         dfm = [dfm1, dfm2, dfm3, dfm4]
         for k in (3, 2, 1, 0):
             need = (k > 0) or ctx.x_needs_grad
-            dp = double_conv_bwd(p, saved[k], n, gs, grads, dev, da=dfm[k], dp=dp, need_input_grad=need)
+            # the gradient w.r.t. a level's pooled input is the dp of the level above: stored as that input is
+            dp = double_conv_bwd(p, saved[k], n, gs, grads, dev, da=dfm[k], dp=dp, need_input_grad=need,
+                                 dx_bf=bool(k > 0 and saved[k]['views'][0].bf))
         return (None, dp) + grads.result(state['names'])
 
 
@@ -311,15 +338,18 @@ class UnetDecodeFn(torch.autograd.Function):
             sk = skips[4 - k]
             if sk.H != 2 * H:
                 raise NotImplementedError('Up padding (unet.py:76-81) is only needed for odd sizes')
+            # bf16 mode: y1 of an Up block and the last block's y2 (read by OutConv's streaming kernels); the y2 of up1..3
+            # feeds the next ConvTranspose2d, which runs on the fp32 tile engine, and stays fp32 (as does u)
+            bk = bf_ok(state.get('act_dtype', 'f32'), co, 2 * H, 2 * H)
             sv, vn = double_conv_fwd(p, f'expansion.up{k}.conv', [sk, View(u, ci // 2, 2 * H, 2 * H)], co, n, gs,
-                                     training, bufs, dev)
+                                     training, bufs, dev, bf=(bk, bk and k == 4))
             ups.append(dict(vin=v, dc=sv, ci=ci, H=H))
             v = vn
         Wo, bo = p['expansion.outc.conv.weight'], p['expansion.outc.conv.bias']
         Cout = Wo.shape[0]
         out = _empty(n, Cout, v.H, v.W, dev=dev)
         L.call('mo_nchw_conv1x1_fwd', L.ptr(v.t), v.istride, v.C, L.ptr(v.sc), L.ptr(v.sh), 1, gs, L.ptr(Wo), L.ptr(bo),
-               Cout, n, v.H * v.W, L.ptr(out), Cout * v.H * v.W, st)
+               Cout, n, v.H * v.W, L.ptr(out), Cout * v.H * v.W, L.BF_IN0 * v.bf, st)
         ctx.state, ctx.p, ctx.fc_sv, ctx.ups, ctx.vlast, ctx.n = state, p, fc_sv, ups, v, n
         return out
 
@@ -340,9 +370,10 @@ class UnetDecodeFn(torch.autograd.Function):
         ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), n * Cout * 2), device=dev,
                          dtype=torch.float32)
         L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Cout * HW, Cout, L.ptr(v.t), v.istride, C4, L.ptr(v.sc),
-               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), st)
-        da = _empty(n, C4, v.H, v.W, dev=dev)
-        L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW, st)
+               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), L.BF_IN0 * v.bf, st)
+        da = _empty(n, C4, v.H, v.W, dev=dev, bf=bool(v.bf))
+        L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW,
+               L.BF_OUT * v.bf, st)
         dfm = [None] * 4
         for k in (4, 3, 2, 1):
             up = ctx.ups[k - 1]

@@ -27,10 +27,16 @@ def act_view(y, sc, sh, gsize):
                                                 # two input-channel chunks (ragged second chunk), 32 output channels, many images per workgroup
                                                 (4, 2, 13, 0, 4, 64, 64), (3, 1, 8, 0, 8, 16, 128), (2, 2, 4, 4, 4, 24, 64), (2, 1, 16, 16, 16, 64, 64),
                                                 (2, 2, 12, 8, 32, 32, 64), (40, 2, 4, 0, 4, 64, 128), (2, 1, 5, 0, 16, 8, 64)])
-def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W):
+@pytest.mark.parametrize('bf', [0, 1])
+def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
+    """bf=1: the same layer with its activation tensors (in0, out, dy; in1 = the fp32 upsampled map of an Up block)
+    stored as bf16 -- only on shapes the streaming kernels serve (include/mo_hip.h `dtypes`)."""
     lib = L.load()
+    if bf and not (Co <= 32 and H % 8 == 0 and W % 64 == 0 and H >= 32):
+        pytest.skip('bf16 storage exists on the direct / MFMA kernels only')
     G = n // gs
-    x0 = rand(1, (n, C0, H, W)).requires_grad_(True)
+    q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    x0 = q(rand(1, (n, C0, H, W))).requires_grad_(True)
     sc0, sh0 = rand(2, (G, C0)) * 0.3 + 1, rand(3, (G, C0)) * 0.3
     a0 = act_view(x0, sc0, sh0, gs)
     ins = [a0]
@@ -39,48 +45,55 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W):
         ins.append(x1)
     Wt = (rand(5, (Co, C0 + C1, 3, 3)) / np.sqrt(9 * (C0 + C1))).requires_grad_(True)
     ref = F.conv2d(torch.cat(ins, 1), Wt, None, padding=1)
-    out = torch.empty(n, Co, H, W, device='cuda')
-    x0d = dev(x0.detach())
+    out = torch.empty(n, Co, H, W, device='cuda', dtype=torch.bfloat16 if bf else torch.float32)
+    x0d = dev(x0.detach().to(torch.bfloat16) if bf else x0.detach())
     x1d = dev(x1.detach()) if C1 else None
     args_in = (L.ptr(x0d), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1,
                L.ptr(x1d), C1, C1 * H * W, None, None, 0)
     ntile = lib.mo_conv3x3_stats_tiles(Co, n, H, W)
     stats = torch.full((n, max(ntile, 1), Co, 2), float('nan'), device='cuda')
     L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(dev(Wt.detach())), Co, n, H, W, L.ptr(out), Co * H * W,
-           L.ptr(stats) if ntile else None, L.stream())
-    close(out, ref, what='conv fwd')
+           L.ptr(stats) if ntile else None, (L.BF_IN0 | L.BF_OUT) if bf else 0, L.stream())
+    close(out.float(), ref, tol=4e-3 if bf else 1e-4, what='conv fwd')          # bf16 result: half an ulp = 2^-9
     if ntile:
         # BatchNorm statistics from the conv epilogue: per-tile (sum, sum of squares) rows add up to the per-image sums
         st = stats.cpu().double().sum(1)
         rd = ref.detach().double()
         close(st[..., 0], rd.sum((2, 3)), tol=1e-5, what='epilogue sum')
         close(st[..., 1], (rd * rd).sum((2, 3)), tol=1e-5, what='epilogue sumsq')
-    dy = rand(6, tuple(ref.shape))
+    dy = q(rand(6, tuple(ref.shape)))
     ref.backward(dy)
     # data gradient = conv of dy with the flipped/transposed weights -> gradient w.r.t. the *activated* cat
     Ci = C0 + C1
     Wf = torch.empty(Ci, Co, 3, 3, device='cuda')
     L.call('mo_conv3x3_flip_weights', L.ptr(dev(Wt.detach())), Co, Ci, L.ptr(Wf), L.stream())
-    dcat = torch.empty(n, Ci, H, W, device='cuda')
-    L.call('mo_conv3x3_fwd', L.ptr(dev(dy)), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wf), Ci,
-           n, H, W, L.ptr(dcat), Ci * H * W, None, L.stream())
-    dcat_ref = F.conv_transpose2d(dy, Wt.detach(), padding=1)
-    close(dcat, dcat_ref, what='conv bwd data')
-    if C1:
-        close(dcat[:, C0:], x1.grad, what='dx1')
+    dyd = dev(dy.to(torch.bfloat16) if bf else dy)
+    for obf in ((0, 1) if bf else (0,)):                   # data gradient into an fp32 tensor (Up blocks) or a bf16 one
+        dcat = torch.empty(n, Ci, H, W, device='cuda', dtype=torch.bfloat16 if obf else torch.float32)
+        L.call('mo_conv3x3_fwd', L.ptr(dyd), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wf), Ci,
+               n, H, W, L.ptr(dcat), Ci * H * W, None, (L.BF_IN0 * bf) | (L.BF_OUT * obf), L.stream())
+        dcat_ref = F.conv_transpose2d(dy, Wt.detach(), padding=1)
+        close(dcat.float(), dcat_ref, tol=4e-3 if obf else 1e-4, what='conv bwd data')
+        if C1:
+            close(dcat[:, C0:].float(), x1.grad, tol=4e-3 if obf else 1e-4, what='dx1')
     dW = torch.empty(Co, Ci, 3, 3, device='cuda')
     ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * H * W), device='cuda')
-    L.call('mo_conv3x3_bwd_weight', L.ptr(dev(dy)), Co * H * W, Co, *args_in, gs, n, H, W, L.ptr(dW), L.ptr(ws), L.stream())
+    L.call('mo_conv3x3_bwd_weight', L.ptr(dyd), Co * H * W, Co, *args_in, gs, n, H, W, L.ptr(dW), L.ptr(ws),
+           (L.BF_DY | L.BF_IN0) if bf else 0, L.stream())
     close(dW, Wt.grad, what='conv dW')
 
 
 @pytest.mark.parametrize('n,gs,C,H,W,pool,use_da', [(6, 3, 4, 16, 16, True, True), (4, 2, 8, 8, 8, True, False),
                                                     (4, 1, 16, 8, 12, False, True), (2, 2, 64, 8, 8, False, True)])
-def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da):
-    """[conv out] -> BatchNorm2d (train, per group of gs images) -> ReLU (-> MaxPool2d(2)) and backward."""
+@pytest.mark.parametrize('bf', [0, 1])
+def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da, bf):
+    """[conv out] -> BatchNorm2d (train, per group of gs images) -> ReLU (-> MaxPool2d(2)) and backward.
+    bf=1: y, da, dp, the pooled output and dy stored as bf16."""
     lib = L.load()
     G = n // gs
-    y = rand(10, (n, C, H, W)).requires_grad_(True)
+    q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    hb = (lambda t: t.to(torch.bfloat16)) if bf else (lambda t: t)
+    y = q(rand(10, (n, C, H, W))).requires_grad_(True)
     gamma = (rand(11, (C,)) * 0.3 + 1).requires_grad_(True)
     beta = (rand(12, (C,)) * 0.3).requires_grad_(True)
     rm0, rv0 = rand(13, (C,)) * 0.1, rand(14, (C,)).abs() + 0.5
@@ -89,9 +102,9 @@ def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da):
     for g in range(G):                                   # reference: one BN call per group, in order
         acts.append(F.relu(F.batch_norm(y[g * gs:(g + 1) * gs], rm, rv, gamma, beta, True, 0.1, 1e-5)))
     a = torch.cat(acts, 0)
-    yd = dev(y.detach())
+    yd = dev(hb(y.detach()))
     stats = torch.empty(n, C, 2, device='cuda')
-    L.call('mo_nchw_stats', L.ptr(yd), C * H * W, C, n, H * W, L.ptr(stats), L.stream())
+    L.call('mo_nchw_stats', L.ptr(dev(y.detach())), C * H * W, C, n, H * W, L.ptr(stats), L.stream())
     rmd, rvd = dev(rm0.clone()), dev(rv0.clone())
     aff = torch.empty(4, G, C, device='cuda')
     gd, bd = dev(gamma.detach()), dev(beta.detach())
@@ -100,28 +113,28 @@ def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da):
     close(rmd, rm, 1e-5, 'running_mean (sequential group updates)')
     close(rvd, rv, 1e-5, 'running_var')
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-    out = torch.empty(n, C, Ho, Wo, device='cuda')
+    out = torch.empty(n, C, Ho, Wo, device='cuda', dtype=torch.bfloat16 if bf else torch.float32)
     L.call('mo_unet_act', L.ptr(yd), C * H * W, C, n, H, W, L.ptr(aff[0]), L.ptr(aff[1]), gs, 1 if pool else 0,
-           L.ptr(out), C * Ho * Wo, L.stream())
+           L.ptr(out), C * Ho * Wo, (L.BF_IN0 | L.BF_OUT) if bf else 0, L.stream())
     ref_out = F.max_pool2d(a, 2) if pool else a
-    close(out, ref_out, what='act/pool')
+    close(out.float(), ref_out, tol=4e-3 if bf else 1e-4, what='act/pool')
     # backward: loss = <a, da> + <pool(a), dp>
-    da = rand(15, (n, C, H, W)) if use_da else None
-    dp = rand(16, (n, C, H // 2, W // 2)) if pool else None
+    da = q(rand(15, (n, C, H, W))) if use_da else None
+    dp = q(rand(16, (n, C, H // 2, W // 2))) if pool else None
     loss = 0
     if use_da:
         loss = loss + (a * da).sum()
     if pool:
         loss = loss + (F.max_pool2d(a, 2) * dp).sum()
     loss.backward()
-    dy = torch.empty(n, C, H, W, device='cuda')
+    dy = torch.empty(n, C, H, W, device='cuda', dtype=torch.bfloat16 if bf else torch.float32)
     dgam = torch.empty(C, device='cuda'); dbet = torch.empty(C, device='cuda')
     ws = torch.empty(lib.mo_unet_act_bwd_ws_floats(n, C), device='cuda')
     L.call('mo_unet_act_bwd', L.ptr(yd), C * H * W, C, n, H, W, gs, L.ptr(gd), L.ptr(aff[2]), L.ptr(aff[3]),
-           L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(dev(da)) if use_da else None, C * H * W,
-           L.ptr(dev(dp)) if pool else None, C * (H // 2) * (W // 2), L.ptr(dy), C * H * W, L.ptr(dgam), L.ptr(dbet),
-           L.ptr(ws), L.stream())
-    close(dy, y.grad, what='dy')
+           L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(dev(hb(da))) if use_da else None, C * H * W,
+           L.ptr(dev(hb(dp))) if pool else None, C * (H // 2) * (W // 2), L.ptr(dy), C * H * W, L.ptr(dgam), L.ptr(dbet),
+           L.ptr(ws), (L.BF_IN0 | L.BF_IN1 | L.BF_DP | L.BF_OUT) if bf else 0, L.stream())
+    close(dy.float(), y.grad, tol=4e-3 if bf else 1e-4, what='dy')
     close(dgam, gamma.grad, what='dgamma')
     close(dbet, beta.grad, what='dbeta')
 
@@ -163,33 +176,38 @@ def test_convt2x2_fwd_bwd(L, n, gs, Ci, Co, H, W, act):
 
 @pytest.mark.parametrize('n,gs,Ci,Co,HW', [(4, 2, 4, 1, 256), (2, 1, 4, 3, 64), (6, 2, 4, 13, 64 * 64), (4, 2, 8, 8, 1028),
                                           (2, 2, 13, 4, 2048), (2, 1, 24, 20, 256), (3, 3, 4, 16, 5000)])
-def test_outconv_fwd_bwd(L, n, gs, Ci, Co, HW):
+@pytest.mark.parametrize('bf', [0, 1])
+def test_outconv_fwd_bwd(L, n, gs, Ci, Co, HW, bf):
+    """bf=1: the input view (the last DoubleConv's raw output) and the data gradient stored as bf16."""
     lib = L.load()
+    if bf and (Ci > 16 or Co > 16):
+        pytest.skip('bf16 storage exists on the streaming kernels only')
     G = n // gs
-    x = rand(30, (n, Ci, HW, 1)).requires_grad_(True)
+    x = rand(30, (n, Ci, HW, 1))
+    x = (x.to(torch.bfloat16).float() if bf else x).requires_grad_(True)
     sc, sh = rand(31, (G, Ci)) * 0.3 + 1, rand(32, (G, Ci)) * 0.3
     a = act_view(x, sc, sh, gs)
     a.retain_grad()
     Wt = rand(33, (Co, Ci, 1, 1)).requires_grad_(True)
     b = rand(34, (Co,)).requires_grad_(True)
     ref = F.conv2d(a, Wt, b)
-    xd, scd, shd = dev(x.detach()), dev(sc), dev(sh)
+    xd, scd, shd = dev(x.detach().to(torch.bfloat16) if bf else x.detach()), dev(sc), dev(sh)
     out = torch.empty(n, Co, HW, device='cuda')
     L.call('mo_nchw_conv1x1_fwd', L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, L.ptr(dev(Wt.detach())),
-           L.ptr(dev(b.detach())), Co, n, HW, L.ptr(out), Co * HW, L.stream())
+           L.ptr(dev(b.detach())), Co, n, HW, L.ptr(out), Co * HW, L.BF_IN0 * bf, L.stream())
     close(out, ref.reshape(n, Co, HW), what='outc fwd')
     dout = rand(35, tuple(ref.shape))
     ref.backward(dout)
     dd = dev(dout)
-    din = torch.empty(n, Ci, HW, device='cuda')
+    din = torch.empty(n, Ci, HW, device='cuda', dtype=torch.bfloat16 if bf else torch.float32)
     L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dd), Co * HW, Co, L.ptr(dev(Wt.detach())), Ci, n, HW, L.ptr(din), Ci * HW,
-           L.stream())
-    close(din, a.grad.reshape(n, Ci, HW), what='outc bwd data')
+           L.BF_OUT * bf, L.stream())
+    close(din.float(), a.grad.reshape(n, Ci, HW), tol=4e-3 if bf else 1e-4, what='outc bwd data')
     dW = torch.empty(Co, Ci, device='cuda')
     db = torch.empty(Co, device='cuda')
     ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Co, Ci, n * HW), n * Co * 2), device='cuda')
     L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dd), Co * HW, Co, L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, n,
-           HW, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+           HW, L.ptr(dW), L.ptr(db), L.ptr(ws), L.BF_IN0 * bf, L.stream())
     close(dW, Wt.grad.reshape(Co, Ci), what='outc dW')
     close(db, b.grad, what='outc db')
 
