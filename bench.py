@@ -167,15 +167,16 @@ def cpu_baseline(supports, max_steps=5, batch=4, budget_s=25.0):
             "gpu_loss_same_steps": gpu_matched_loss(schema, supports, x, y, steps + 1)}
 
 
-def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=256):
+def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=256, act_dtype='bf16'):
     """Secondary metric of BASELINE.json ("+ UNet tiles/sec"): Modified_UNET training step (forward + MSE/metrics +
-    backward + all-reduce + Adam) on synthetic (B,67,H,13,256,256) GOES-style tiles (config 3), fp32, batch-sharded
+    backward + all-reduce + Adam) on synthetic (B,67,H,13,256,256) GOES-style tiles (config 3), batch-sharded
     like the gwnet leg.  Returns the object printed under "unet"."""
     from multimodal_outage_amd.models.unet import Modified_UNET
     from multimodal_outage_amd.lit import mse_and_metrics
     from multimodal_outage_amd.trainer import FlatTrainer
     torch.manual_seed(42)
     m = Modified_UNET('gwnet', horizon, input_channels=cin, output_channels=cin, image_dimension=size).to(dev).train()
+    m.act_dtype = act_dtype      # BASELINE config 3 names bf16: activation storage bf16, arithmetic fp32
     tr = FlatTrainer(m).attach()
     g = torch.Generator().manual_seed(2000 + int(os.environ.get('RANK', '0')))
     x = torch.randn(batch, 67, horizon, cin, size, size, generator=g).to(dev)
@@ -235,7 +236,8 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
             "vector_TFLOPs": round(3 * UNET_FLOP_FWD_PER_TILE * scale * tps / world / 1e12, 2), "traffic": None}
     return {"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(tps, 1), "unit": "tiles/s", "roofline": roof,
             "ms_per_step": round(dt / steps * 1e3, 2), "tiles_per_step_per_gpu": tiles, "steps": steps, "warmup": warmup,
-            "trace": trace, "dtype": "f32", "data": "synthetic",
+            "trace": trace, "dtype": ("bf16 activation storage at >= 64x64, fp32 arithmetic" if act_dtype == 'bf16' else "f32"),
+            "data": "synthetic",
             "config": {"workload": f"Modified_UNET fwd+MSE+bwd+Adam on ({batch},67,{horizon},{cin},{size},{size}) tiles",
                        "tile": f"{cin}x{size}x{size}", "counties": 67, "horizon": horizon, "parallelism": f"dp{world}"},
             "loss": round(float(loss.detach()), 5)}

@@ -7,7 +7,7 @@
 #pragma once
 #include "mo_common.h"
 
-#define UD_CK 8          // input channels per LDS stage
+#define UD_CK 4          // input channels per LDS stage
 
 // ---- activation storage: fp32, or bf16 ("bf16 mode" of BASELINE config 3: the raw conv outputs and their gradients at
 // the large resolutions live in HBM as bf16, every kernel widens on load, computes in fp32 and narrows on store with

@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--cin', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16', help="activation storage (Modified_UNET.act_dtype)")
     a = ap.parse_args()
     import multimodal_outage_amd._lib as L
     L.load()
@@ -27,6 +28,7 @@ def main():
     from multimodal_outage_amd.trainer import FlatTrainer
     torch.manual_seed(42)
     m = Modified_UNET('gwnet', a.horizon, input_channels=a.cin, output_channels=a.cin, image_dimension=a.size).cuda().train()
+    m.act_dtype = a.dtype
     tr = FlatTrainer(m).attach()
     B, H, S = a.batch, a.horizon, a.size
     x = torch.randn(B, 67, H, a.cin, S, S, device='cuda')
@@ -54,7 +56,7 @@ def main():
     print(json.dumps({"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(tiles / dt, 1), "unit": "tiles/s",
                       "ms_per_step": round(dt / a.steps * 1e3, 2), "tiles_per_step": B * 67 * H,
                       "config": {"batch": B, "horizon": H, "tile": f"{a.cin}x{S}x{S}", "counties": 67},
-                      "loss": round(float(loss), 5), "dtype": "f32"}))
+                      "loss": round(float(loss), 5), "dtype": a.dtype}))
 
 
 if __name__ == '__main__':
