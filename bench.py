@@ -40,15 +40,17 @@ PEAK_HBM_GBPS = 8000.0
 
 def pmc_traffic(dtype, batch):
     """HBM-side bytes per launch of the dense-product kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
     command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950).
     None when no pass matches this dtype/batch."""
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-        e = d.get(f'{dtype}_b{batch}')
-        return e['bytes_per_launch'] if e else None
-    except Exception:
-        return None
+    for f in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):      # the latest round's passes first
+        try:
+            e = json.load(open(os.path.join(ROOT, 'profiles', f))).get(f'{dtype}_b{batch}')
+            if e:
+                return e['bytes_per_launch']
+        except Exception:
+            pass
+    return None
 
 
 def alg_bytes(dtype):

@@ -1,7 +1,7 @@
 """Turn two rocprofv3 counter-collection passes (FETCH_SIZE and WRITE_SIZE, collected SEPARATELY as
 MI355X_MICROARCH.md prescribes) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-unet` into
   * a per-kernel table  profiles/<tag>_pmc_fetch_write_per_kernel.csv
-  * the entry bench.py reads for roofline.traffic in profiles/r01_pmc_traffic.json (key <dtype>_b<batch>).
+  * the entry bench.py reads for roofline.traffic in profiles/r02_pmc_traffic.json (key <dtype>_b<batch>).
 
   python tools/pmc_summary.py --fetch gpurun_out/pmc_fetch/run_counter_collection.csv \
       --write gpurun_out/pmc_write/run_counter_collection.csv --batch 128 --dtype bf16 --tag r01_final_b128
@@ -61,6 +61,7 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--tag', required=True)
     ap.add_argument('--match', default='gemm_bf16', help='substring of the dominant kernel(s)')
+    ap.add_argument('--out', default='r02_pmc_traffic.json', help='file under profiles/ that bench.py reads')
     a = ap.parse_args()
     ft, fc = per_kernel(a.fetch, 'FETCH_SIZE')
     wt, wc = per_kernel(a.write, 'WRITE_SIZE')
@@ -86,7 +87,7 @@ def main():
                      f"{a.match}* launch (incl. the 2 serial roofline steps and, in the throughput mode, the head's 3 bf16 GEMM launches per step, one of them the split-K weight gradient; "
                      f"algorithmic_bytes_per_launch_avg covers the adjacency products); FETCH_SIZE x2 (gfx950 correction); "
                      f"per-kernel table {os.path.basename(out_csv)}"}
-    jp = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    jp = os.path.join(ROOT, 'profiles', a.out)
     d = json.load(open(jp)) if os.path.exists(jp) else {}
     d[f'{a.dtype}_b{a.batch}'] = entry
     json.dump(d, open(jp, 'w'), indent=1)
