@@ -431,3 +431,109 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv of the DEEP levels (16..64 channels at 32x32 / 16x16 pixels) on the fp32 matrix pipe with an LDS halo tile.
+// These layers are real contractions (K = Ci*9 = 144..576), but as an im2col GEMM on the tile engine they were bound by
+// the per-element index arithmetic of the gather.  Here the gather is an LDS address:
+//   D[co][pixel] += A[co][k] * B[k][pixel],  k = (ci, tap) in chunks of 4 (v_mfma_f32_16x16x4_f32, exact fp32),
+//   A = weights staged k-major in LDS ([k][Co]: lanes read consecutive addresses), B = the activated halo tile
+//   (B[k][pixel] = xs[ci][y + ky][x + kx]: one ds_read_b32 per lane).
+// Workgroup = one TH x TW tile (256 pixels = 16 blocks of 16 pixels of a row; 4 blocks per wave) of one image x all
+// output channels (MB blocks of 16); input channels staged 8 at a time.  Optional BatchNorm statistics per tile from
+// the accumulators, as in ud_conv3x3_kernel.  The data gradient is this kernel on dy with the flipped weights.
+// ------------------------------------------------------------------------------------------------
+#define UX_CIC 8
+template <int MB, int TW>
+__global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
+  constexpr int TH = 256 / TW;
+  constexpr int LDT = TW + 8;
+  constexpr int PS = (TH + 2) * LDT;
+  constexpr int CP = 16 * MB;
+  constexpr int BPR = TW / 16;                                   // 16-pixel blocks per tile row
+  __shared__ __attribute__((aligned(16))) float xs[UX_CIC * PS];
+  __shared__ __attribute__((aligned(16))) float wsm[UX_CIC * 9 * CP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const long img = blockIdx.z;
+  const long grp = img / a.gsize;
+  const int Ci = a.C0 + a.C1;
+  const int lj = lane & 15, lk = lane >> 4;
+  uw_f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (uw_f32x4){0.f, 0.f, 0.f, 0.f};
+  int poff[4];                                                   // LDS offset of this lane's pixel in each of its blocks
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int blk = 4 * wave + nb;
+    poff[nb] = (blk / BPR) * LDT + (blk % BPR) * 16 + lj + 3;
+  }
+  for (int c0 = 0; c0 < Ci; c0 += UX_CIC) {
+    const int nc = min(UX_CIC, Ci - c0);
+    __syncthreads();
+    ud_stage_halo<TH, TW, LDT>(xs, a, img, grp, c0, nc, y0, x0, tid);
+    for (int idx = tid; idx < nc * 9 * CP; idx += 256) {
+      const int k = idx / CP, co = idx - k * CP;
+      const int c = k / 9, tap = k - 9 * c;
+      wsm[idx] = (co < a.Co) ? a.W[((long)co * Ci + c0 + c) * 9 + tap] : 0.f;
+    }
+    __syncthreads();
+    const int nk = nc * 9;
+    for (int ks = 0; ks < nk; ks += 4) {
+      const int k = ks + lk;
+      const bool ok = k < nk;
+      const int kk = ok ? k : 0;
+      const int c = kk / 9, tap = kk - 9 * c, ky = tap / 3, kx = tap - 3 * ky;
+      const int boff = c * PS + ky * LDT + kx;
+      const float m = ok ? 1.f : 0.f;
+      float af[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) af[mb] = wsm[kk * CP + mb * 16 + lj] * m;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const float bv = xs[boff + poff[nb]];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bv, acc[mb][nb], 0, 0, 0);
+      }
+    }
+  }
+  // D[i = co][j = pixel]: lane holds column j = lane & 15, rows 4 * (lane >> 4) + r
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = mb * 16 + lk * 4 + r;
+      if (co < a.Co) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int blk = 4 * wave + nb;
+          const int y = y0 + blk / BPR, x = x0 + (blk % BPR) * 16 + lj;
+          const long o = img * a.os + ((long)co * a.H + y) * a.Wd + x;
+          if (a.bfo) { __bf16 t = (__bf16)acc[mb][nb][r]; reinterpret_cast<unsigned short*>(a.out)[o] = __builtin_bit_cast(unsigned short, t); }
+          else a.out[o] = acc[mb][nb][r];
+        }
+      }
+    }
+  if (a.stats) {
+    __shared__ float red[4][2 * CP];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { const float v = acc[mb][nb][r]; s1 += v; s2 += v * v; }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }     // the 16 pixel lanes
+        if (lj == 0) { const int co = mb * 16 + lk * 4 + r; red[wave][2 * co] = s1; red[wave][2 * co + 1] = s2; }
+      }
+    __syncthreads();
+    if (tid < 2 * CP && (tid >> 1) < a.Co) {
+      const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x, ntile = (long)gridDim.x * gridDim.y;
+      a.stats[((img * ntile + tile) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+  }
+}

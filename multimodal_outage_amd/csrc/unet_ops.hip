@@ -20,9 +20,11 @@
 #define MO_BF_DY 8
 #define MO_BF_DP 16
 static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 = previous VALU / split-K weight gradients
+static int mo_opt_no_mfma_conv = 0;      // 1 = deep-level convs on the im2col tile engine / VALU direct kernel as before
 extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!name) return MO_EINVAL;
   if (!strcmp(name, "no_mfma_wgrad")) { mo_opt_no_mfma_wgrad = value; return MO_OK; }
+  if (!strcmp(name, "no_mfma_conv")) { mo_opt_no_mfma_conv = value; return MO_OK; }
   return MO_EINVAL;
 }
 
@@ -152,7 +154,18 @@ static bool ud_conv_direct(const float* in0, long istride0, const float* in1, in
 }
 // Number of per-tile statistics rows per image that mo_conv3x3_fwd writes for this shape when given a `stats` buffer
 // ([n_img][tiles][Co][2] floats); 0 = this shape runs on the implicit-GEMM path, which produces none (use mo_nchw_stats).
+// deep levels on the matrix pipe (ux_conv3x3_mfma_kernel): 17..64 output channels (or <= 32 below 32x32 pixels) on
+// images that tile exactly into 8x32 or 16x16 pixels
+static int ux_tw(int Co, long n_img, int H, int Wd) {
+  if (mo_opt_no_mfma_conv || Co > 64 || n_img >= 65536) return 0;
+  if ((Wd % 32) == 0 && (H % 8) == 0) return 32;
+  if ((Wd % 16) == 0 && (H % 16) == 0) return 16;
+  return 0;
+}
+static bool ux_preferred(int Co, int H, int Wd) { return Co > 16 || H < 32 || Wd < 32; }
 extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd) {
+  const int tw = ux_tw(Co, n_img, H, Wd);
+  if (tw && ux_preferred(Co, H, Wd)) return (Wd / tw) * (H / (256 / tw));
   if (!(Co <= 32 && H >= 32 && Wd >= 32 && n_img < 65536 && (Wd % 4) == 0)) return 0;
   const bool wide = Wd >= 64;
   return mo_cdiv(Wd, wide ? 64 : 32) * mo_cdiv(H, wide ? 16 : 32);
@@ -167,6 +180,24 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
   MO_CHECK_ARG(P < (1L << 31) && istride0 < (1L << 31) && ostride < (1L << 31));
   const int Ci = C0 + C1;
   // thin layers at >= 32x32 pixels: direct convolution on LDS spatial tiles (unet_direct.hpp)
+  const bool al16 = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0)) &&
+                    (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0;
+  const int uxw = al16 ? ux_tw(Co, n_img, H, Wd) : 0;
+  if (uxw && ux_preferred(Co, H, Wd)) {
+    UdConvArgs a;
+    a.stats = stats;
+    a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0; a.bfo = (dtypes & MO_BF_OUT) != 0;
+    a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
+    a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
+    a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+    hipStream_t st = ST(stream);
+    dim3 grid(Wd / uxw, H / (256 / uxw), (unsigned)n_img);
+#define UX_LAUNCH(MB) do { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32>), grid, dim3(256), 0, st, a); \
+                           else hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 16>), grid, dim3(256), 0, st, a); } while (0)
+    if (Co <= 16) UX_LAUNCH(1); else if (Co <= 32) UX_LAUNCH(2); else if (Co <= 48) UX_LAUNCH(3); else UX_LAUNCH(4);
+#undef UX_LAUNCH
+    return mo_launch_status();
+  }
   if (ud_conv_direct(in0, istride0, in1, C1, istride1, Co, n_img, H, Wd, out, ostride)) {
     UdConvArgs a;
     a.stats = stats;

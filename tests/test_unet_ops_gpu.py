@@ -26,7 +26,11 @@ def act_view(y, sc, sh, gsize):
                                                 # MFMA weight-gradient path (W % 64 == 0, H % 8 == 0): 3 / 5 / 9 m-blocks, two views,
                                                 # two input-channel chunks (ragged second chunk), 32 output channels, many images per workgroup
                                                 (4, 2, 13, 0, 4, 64, 64), (3, 1, 8, 0, 8, 16, 128), (2, 2, 4, 4, 4, 24, 64), (2, 1, 16, 16, 16, 64, 64),
-                                                (2, 2, 12, 8, 32, 32, 64), (40, 2, 4, 0, 4, 64, 128), (2, 1, 5, 0, 16, 8, 64)])
+                                                (2, 2, 12, 8, 32, 32, 64), (40, 2, 4, 0, 4, 64, 128), (2, 1, 5, 0, 16, 8, 64),
+                                                # deep levels on the matrix pipe (ux_conv3x3_mfma_kernel): 1..4 blocks of 16 output channels,
+                                                # 8x32 and 16x16 tiles, two views, ragged channel chunks
+                                                (2, 1, 16, 0, 32, 32, 32), (2, 2, 32, 0, 64, 16, 16), (2, 1, 32, 32, 32, 32, 32),
+                                                (3, 1, 24, 8, 48, 16, 32), (2, 2, 8, 0, 20, 64, 64), (2, 1, 13, 0, 8, 16, 16)])
 @pytest.mark.parametrize('bf', [0, 1])
 def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
     """bf=1: the same layer with its activation tensors (in0, out, dy; in1 = the fp32 upsampled map of an Up block)
