@@ -454,13 +454,17 @@ __global__ void linear_splitk_reduce_kernel(const float* __restrict__ ws, long s
   for (int z = 0; z < nz; ++z) s += ws[(long)z * stride + i];
   out[i] = relu ? fmaxf(s, 0.f) : s;
 }
+// row tile of the few-row Linear kernels: 134 rows (67 counties x 2 days) on 128-row tiles are two tiles, the second
+// 95 % padding -- the exact-fp32 MFMA then does twice the work and the layer is compute bound on padding; 32-row tiles
+// pad 134 to 160
+static int linear_bm(long P) { return (mo_cdiv(P, 32) * 32L * 5 <= mo_cdiv(P, 128) * 128L * 4) ? 32 : 128; }
 static int linear_splitk_plan(long P, int N, int K, int& nz, int& kchunk) {
-  const long tiles = (long)mo_cdiv(P, 128) * mo_cdiv(N, 128);
-  long want = 512 / tiles; if (want < 1) want = 1;
+  const long tiles = (long)mo_cdiv(P, linear_bm(P)) * mo_cdiv(N, 128);
+  long want = 768 / tiles; if (want < 1) want = 1;
   long maxz = K / 512; if (maxz < 1) maxz = 1;                 // at least 512 of K per slab
   if (want > maxz) want = maxz;
   if (want > 64) want = 64;
-  kchunk = (int)(((K + want - 1) / want + 15) / 16 * 16);
+  kchunk = (int)(((K + want - 1) / want + 31) / 32 * 32);
   nz = (K + kchunk - 1) / kchunk;
   return nz;
 }
@@ -503,7 +507,9 @@ extern "C" int mo_conv1x1_fwd_splitk(const float* in, int Ci, const float* W, co
   MoOperand Bo = op_simple(W, Ci, Co, Ci);     // XROWS: rows = n = co, cols = k = ci
   MoEpi E; epi_init(E, ws, Co);
   E.slab_stride = P * (long)Co; E.kchunk = kchunk;
-  int rc = launch<128, 128, 16, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Co, nz, ST(stream));
+  int rc = (linear_bm(P) == 32)
+               ? launch<32, 128, 32, 1, 4, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Co, nz, ST(stream))
+               : launch<128, 128, 16, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P, Co, nz, ST(stream));
   if (rc) return rc;
   const long n = P * (long)Co;
   hipLaunchKernelGGL(linear_splitk_reduce_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), ws, n, nz, b, Co,
@@ -519,7 +525,9 @@ extern "C" int mo_conv1x1_bwd_data_splitk(const float* dout, int Co, long P, con
   MoOperand Bo = op_simple(W, Ci, Co, Ci);      // KROWS: rows = k = co, cols = n = ci
   MoEpi E; epi_init(E, ws, Ci);
   E.slab_stride = P * (long)Ci; E.kchunk = kchunk;
-  int rc = launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, nz, ST(stream));
+  int rc = (linear_bm(P) == 32)
+               ? launch<32, 128, 32, 1, 4, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, nz, ST(stream))
+               : launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, nz, ST(stream));
   if (rc) return rc;
   const long n = P * (long)Ci;
   hipLaunchKernelGGL(linear_splitk_reduce_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), ws, n, nz,
@@ -607,14 +615,17 @@ static int wgrad_run(const MoOperand& A, const MoOperand& Bo, long P, int M, int
   }
   int nsplit, kchunk; wgrad_plan(M, N, P, nsplit, kchunk);
   if (nslab) *nslab = nsplit;
-  MoEpi E; epi_init(E, ws, N);
+  // one K slice (few rows against a wide weight matrix: the Encoder / Decoder fc layers, 134 rows x 4096 x 16384):
+  // the tile goes straight to dW -- a slab + reduction would write and re-read the whole 268 MB gradient once more
+  const bool direct = nsplit == 1 && dW != nullptr;
+  MoEpi E; epi_init(E, direct ? dW : ws, N);
   E.slab_stride = (long)M * N; E.kchunk = kchunk;
   const bool fused = db && op_fast_ok(A) && op_fast_ok(Bo);
-  float* cs = ws + (long)nsplit * M * N;
+  float* cs = ws + (direct ? 0 : (long)nsplit * M * N);
   if (fused) E.colsum = cs;
   int rc = launch<64, 64, 32, 2, 2, MO_KROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, M, N, nsplit, st);
   if (rc) return rc;
-  if (dW) {
+  if (dW && !direct) {
     long n = (long)M * N;
     hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(n), dim3(256), 0, st, ws, n, nsplit, dW, n);
   }
