@@ -130,6 +130,29 @@ def test_modified_unet_bf16_storage_mode(name, B, channels, size, seed):
     assert all(torch.isfinite(v.grad).all() for v in m.parameters() if v.grad is not None)
 
 
+def test_flat_trainer_attach_writes_the_same_gradients():
+    """FlatTrainer.attach(): the UNet-side Functions write their gradients straight into the flat gradient buffer (no
+    AccumulateGrad kernels) -- the result must be bit-identical to the gradients autograd accumulates without it, the
+    Graph WaveNet inside (called once per batch element, unet.py:221) still accumulating through autograd."""
+    from multimodal_outage_amd.trainer import FlatTrainer
+    x = rand(401, (2, 67, 2, 1, 128, 128)).cuda()
+    tdim = rand(403, (2, 67, 2, 64)).cuda()
+    tgt = rand(402, (2, 67, 2, 1, 128, 128)).cuda()
+    got = {}
+    for mode in ('autograd', 'attach'):
+        m = _model().train()
+        tr = FlatTrainer(m)
+        if mode == 'attach':
+            tr.attach()
+            assert m._mo_grad_out and not any(k.startswith('st_gnn.') for k in m._mo_grad_out)
+        for _ in range(2):                                  # two steps: the second must not see leftovers of the first
+            tr.zero_grad()
+            F.mse_loss(m(x, tdim), tgt).backward()
+        got[mode] = tr.flat_g.clone()
+    assert torch.equal(got['autograd'], got['attach'])
+    assert float(got['attach'].abs().max()) > 0
+
+
 def test_lit_training_step_surface():
     """lit.py:29-43: batch = (x, y, x_time) with x,y (B,H,67,1,128,128); returns the MSE loss and logs
     train_loss/mae/mape/rmse; the fused loss kernel matches nn.MSELoss and the torchmetrics definitions."""
