@@ -287,6 +287,13 @@ int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint32_t thresh,
 /* ReLU backward on a materialised activation y: out = (y > 0) ? dy : 0 (fc layers, unet.py:142-144) */
 int mo_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream);
 
+/* ---- input rasters (the step in front of the path; BlackMarbleDataset's per-image transform, utils.py:35-38,59-64):
+ * raw (n, h, w) radiance -> out (n, oh, ow): fill_value -> 0, bilinear antialiased resize (what torchvision 0.18's
+ * transforms.Resize does to a float tensor: F.interpolate(mode='bilinear', align_corners=False, antialias=True)), then
+ * (x - mean) / std. */
+int mo_raster_prepare(const float* raw, long n, int h, int w, float fill_value, float mean, float std, float* out,
+                      int oh, int ow, void* stream);
+
 /* A/B switches of the UNet kernels for measurements: "no_mfma_wgrad" (1: the VALU / split-K 3x3 weight gradients) */
 int mo_unet_set_option(const char* name, int value);
 

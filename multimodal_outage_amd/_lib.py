@@ -82,6 +82,7 @@ SIGNATURES = {
                               vp, vp, vp, i32, vp]),
     'mo_nchw_channel_sum': (i32, [vp, i64, i32, i64, i32, vp, vp, vp]),
     'mo_maxpool2_bwd': (i32, [vp, i64, i32, i64, i32, i32, vp, i64, vp, i64, vp]),
+    'mo_raster_prepare': (i32, [vp, i64, i32, i32, f32, f32, f32, vp, i32, i32, vp]),
     'mo_dropout': (i32, [vp, vp, i64, u32, u32, f32, vp]),
     'mo_relu_bwd': (i32, [vp, vp, vp, i64, vp]),
     # ---- RCCL exchange step / host CSR builder

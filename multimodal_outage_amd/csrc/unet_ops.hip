@@ -827,3 +827,57 @@ extern "C" int mo_relu_bwd(const float* dy, const float* y, float* out, long n, 
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, ST(stream), dy, y, out, n);
   return mo_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input rasters (the step in front of the hot path): BlackMarbleDataset's per-image transform
+// (utils.py:35-38,59-64) on the device -- fill value 6553.5 -> 0, transforms.Resize((S,S)) of torchvision 0.18 on a
+// float tensor (= F.interpolate(mode='bilinear', align_corners=False, antialias=True): a triangle filter whose support
+// grows with the down-scaling factor, weights normalised per output index, separable), then Normalize(mean, std).
+// One thread per output pixel; the two 1-D weight sets are evaluated on the fly (<= ~2*scale + 2 taps each).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aa_span(int o, int in_size, float scale, int& lo, int& n, float& center, float& invs) {
+  const float support = scale >= 1.f ? scale : 1.f;                 // bilinear: interp_size 2 -> half-width 1 x scale
+  center = scale * (o + 0.5f);
+  invs = scale >= 1.f ? 1.f / scale : 1.f;
+  lo = max((int)(center - support + 0.5f), 0);
+  n = min((int)(center + support + 0.5f), in_size) - lo;
+}
+__device__ __forceinline__ float aa_w(int j, int lo, float center, float invs) {
+  const float x = fabsf((j + lo - center + 0.5f) * invs);
+  return x < 1.f ? 1.f - x : 0.f;
+}
+__global__ void raster_prepare_kernel(const float* __restrict__ raw, long n, int h, int w, float fill, float mean,
+                                      float inv_std, float* __restrict__ out, int oh, int ow) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * oh * ow) return;
+  const int ox = (int)(i % ow); long r = i / ow;
+  const int oy = (int)(r % oh); const long img = r / oh;
+  const float sy = (float)h / oh, sx = (float)w / ow;
+  int ylo, yn, xlo, xn; float yc, yi, xc, xi;
+  aa_span(oy, h, sy, ylo, yn, yc, yi);
+  aa_span(ox, w, sx, xlo, xn, xc, xi);
+  float wxs = 0.f;
+  for (int b = 0; b < xn; ++b) wxs += aa_w(b, xlo, xc, xi);
+  float wys = 0.f, acc = 0.f;
+  const float* p = raw + img * (long)h * w;
+  for (int a = 0; a < yn; ++a) {
+    const float wy = aa_w(a, ylo, yc, yi);
+    wys += wy;
+    float row = 0.f;
+    for (int b = 0; b < xn; ++b) {
+      float v = p[(long)(ylo + a) * w + xlo + b];
+      if (v == fill) v = 0.f;
+      row += aa_w(b, xlo, xc, xi) * v;
+    }
+    acc += wy * (row / wxs);
+  }
+  out[i] = (acc / wys - mean) * inv_std;
+}
+extern "C" int mo_raster_prepare(const float* raw, long n, int h, int w, float fill_value, float mean, float std,
+                                 float* out, int oh, int ow, void* stream) {
+  MO_CHECK_ARG(raw && out && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && std != 0.f);
+  const long total = n * oh * ow;
+  hipLaunchKernelGGL(raster_prepare_kernel, dim3(mo_cdiv(total, 256)), dim3(256), 0, ST(stream), raw, n, h, w, fill_value,
+                     mean, 1.f / std, out, oh, ow);
+  return mo_launch_status();
+}

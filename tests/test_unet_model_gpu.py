@@ -219,3 +219,31 @@ def test_synthetic_feeder_contract_and_training_step():
     loss = lit.training_step(batch)
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in lit.model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize('h,w,size', [(300, 417, 128), (100, 90, 128), (128, 128, 128), (1000, 37, 128), (513, 640, 256)])
+def test_raster_prepare_matches_the_reference_transform(h, w, size):
+    """BlackMarbleDataset's per-image transform on the device (utils.py:35-38,59-64): no-data value -> 0,
+    transforms.Resize((S,S)), Normalize(mean, std).  torchvision is absent from the image; 0.18 (requirements.txt:13)
+    resizes a float tensor with F.interpolate(mode='bilinear', align_corners=False, antialias=True), which is what the
+    CPU side of this test calls (torchvision's own wrapper: parity unpinned)."""
+    from multimodal_outage_amd.data import prepare_rasters, FILL_VALUE, MEAN, STD
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    raw = -8.0 * torch.log1p(-torch.rand(3, 2, 1, h, w, generator=g) * 0.98)
+    raw[torch.rand(raw.shape, generator=g) < 0.03] = FILL_VALUE
+    x = raw.clone()
+    x[x == FILL_VALUE] = 0                                                   # utils.py:62
+    ref = F.interpolate(x.view(-1, 1, h, w), size=(size, size), mode='bilinear', align_corners=False, antialias=True)
+    ref = ((ref - MEAN) / STD).view(3, 2, 1, size, size)                     # transforms.Normalize
+    out = prepare_rasters(raw.cuda(), size)
+    assert tuple(out.shape) == (3, 2, 1, size, size)
+    assert_close(out, ref, 2e-5, 1e-5, 'raster transform')
+
+
+def test_synthetic_feeder_native_size_goes_through_the_transform():
+    from multimodal_outage_amd.data import SyntheticBlackMarble
+    from multimodal_outage_amd.date2vec import Date2Vec
+    ds = SyntheticBlackMarble(Date2Vec(k=64).cuda(), length=3, horizon=2, native_size=(211, 305))
+    past, future, te = ds[0]
+    assert tuple(past.shape) == (2, 67, 1, 128, 128) and tuple(future.shape) == (2, 67, 1, 128, 128)
+    assert torch.isfinite(past).all() and tuple(te.shape) == (67, 2, 64)
