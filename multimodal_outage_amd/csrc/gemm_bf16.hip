@@ -497,6 +497,65 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
     }
     return;
   }
+  // fp32 result.  Output-bound shapes (the head's K = 256 / 512 products write 1.6 GB per launch) need whole 16-byte
+  // pieces of 1-KB rows in flight, not one 4-byte store per lane and row: the tile leaves in two halves of 128 rows
+  // through the (now idle) 128-KB ring -- accumulator layout in (bias / ReLU applied), rows out; the ReLU gate and the
+  // beta read-modify-write happen on the way out with the same 16-byte pieces, and so does the optional bf16 copy.
+  if ((ldd & 3) == 0 && (((uintptr_t)D) & 15) == 0 && (!mask || (((uintptr_t)mask) & 15) == 0) &&
+      (!Dbf || (((uintptr_t)Dbf) & 7) == 0) && (N & 3) == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* stage = reinterpret_cast<float*>(lds);                  // [128 rows][256 floats], 32-float halves XOR-swizzled
+    for (int half = 0; half < 2; ++half) {
+      if ((wave >> 2) == half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = wn0 + j * 32 + fr;
+            const int n = n0 + col;
+            const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+              float v = acc[i][j][r] + bv;
+              if (relu) v = fmaxf(v, 0.f);
+              stage[row * 256 + (col ^ (((row >> 2) & 1) << 5))] = v;      // the two lane halves (rows +4) on other banks
+            }
+          }
+      }
+      __builtin_amdgcn_s_barrier();
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int id = it * 512 + tid;
+        const int row = id >> 6, c4 = id & 63;
+        const int m = m0 + half * 128 + row, n = n0 + 4 * c4;
+        if (m >= M || n >= N) continue;
+        float4 v = *reinterpret_cast<const float4*>(&stage[row * 256 + ((4 * c4) ^ (((row >> 2) & 1) << 5))]);
+        const long o = (long)m * ldd + n;
+        if (mask) {
+          const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+          if (!(mk.x > 0.f)) v.x = 0.f;
+          if (!(mk.y > 0.f)) v.y = 0.f;
+          if (!(mk.z > 0.f)) v.z = 0.f;
+          if (!(mk.w > 0.f)) v.w = 0.f;
+        }
+        if (beta) {
+          const float4 ov = *reinterpret_cast<const float4*>(D + o);
+          v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+        }
+        *reinterpret_cast<float4*>(D + o) = v;
+        if (Dbf) {
+          __bf16 t0 = (__bf16)v.x, t1 = (__bf16)v.y, t2 = (__bf16)v.z, t3 = (__bf16)v.w;
+          *reinterpret_cast<uint2*>(Dbf + o) =
+              make_uint2((unsigned)__builtin_bit_cast(unsigned short, t0) | ((unsigned)__builtin_bit_cast(unsigned short, t1) << 16),
+                         (unsigned)__builtin_bit_cast(unsigned short, t2) | ((unsigned)__builtin_bit_cast(unsigned short, t3) << 16));
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
