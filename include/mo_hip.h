@@ -128,6 +128,10 @@ int mo_adj_grad(const float* X, const float* dY, int N, long J, float* dA, int b
  * accumulates onto the stored bf16 values).  mo_f32_to_bf16: round-to-nearest-even, n % 8 == 0. */
 int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
                  int N, int K, int beta, void* D_bf16 /* optional bf16 copy of D, may be NULL */, void* stream);
+/* the same 128x128 kernel with the fp32-result epilogue options of mo_gemm_bf16_256_ex (bias[n], ReLU, ReLU-backward
+ * gate by mask > 0): the better kernel for output-bound shapes (short K against a large fp32 result) */
+int mo_gemm_bf16_ex(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M, int N,
+                    int K, int beta, void* D_bf16, const float* bias, int relu, const float* mask, void* stream);
 int mo_f32_to_bf16(const float* x, void* y, long n, void* stream);
 /* 256x256x32-tile variant with a 4-stage LDS-DMA ring (three k-tiles in flight): same contract, plus: A must be
  * readable and zero in columns [K, a_kpad) with a_kpad >= K rounded up to 32 (mo_f32_to_bf16_padded makes such
@@ -146,6 +150,12 @@ int mo_gemm_bf16_256_ex(const void* A, int lda, int a_kpad, const void* B, int l
  * steps of a layer's dg rows: dg[g*Tout + Tout-Tf+t][c] += all[g*Tf+t][col0+c]. */
 int mo_skip_bwd_add(const float* all, int ld, int col0, long G, int Tf, int Tout, float* dg, void* stream);
 
+/* Skip-path weight gradients of all layers in the throughput mode (graph_wavenet.py:164-166 backward): gather the rows of
+ * every layer's gated output that reach the head (its last Tf steps) into one bf16 matrix gcat[G*Tf][32*nl]
+ * (gcat[(grp,t)][32 i + c] = g_i[(grp*Tout_i + Tout_i - Tf + t)][c]); dW_all[Cs][32*nl] = dskip^T gcat is then one
+ * mo_wgrad_bf16_kk launch, and mo_skip_wsplit copies layer i's 32 columns into its (Cs,32) weight gradient. nl <= 8. */
+int mo_skip_gather_bf16(const float* const* g, const int* Tout, int nl, long G, int Tf, void* out_bf16, void* stream);
+int mo_skip_wsplit(const float* dW_all, int Cs, int nl, float* const* dW, void* stream);
 /* Weight gradient of a wide 1x1 conv (end_conv_1, graph_wavenet.py:174-177 backward) in the throughput mode:
  * dW[M][N] = A^T B over K rows with BOTH operands k-major as they lie in HBM (A: bf16 [K][M] output-gradient rows,
  * B: bf16 [K][N] input rows), split-K ring GEMM + fixed-order slab reduction.  K % 32 == 0; M, N, lda, ldb % 8 == 0. */

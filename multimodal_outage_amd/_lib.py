@@ -41,10 +41,13 @@ SIGNATURES = {
     'mo_adj_gemm': (i32, [vp, i32, vp, vp, i64, i32, vp]),
     'mo_adj_grad': (i32, [vp, vp, i32, i64, vp, i32, vp]),
     'mo_gemm_bf16': (i32, [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'mo_gemm_bf16_ex': (i32, [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
     'mo_f32_to_bf16': (i32, [vp, vp, i64, vp]),
     'mo_gemm_bf16_256': (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     'mo_skip_bwd_add': (i32, [vp, i32, i32, i64, i32, i32, vp, vp]),
     'mo_spmm_blk': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, i64, i32, i32, vp]),
+    'mo_skip_gather_bf16': (i32, [vp, vp, i32, i64, i32, vp, vp]),
+    'mo_skip_wsplit': (i32, [vp, i32, i32, vp, vp]),
     'mo_wgrad_bf16_kk_ws_floats': (i64, [i32, i32, i64]),
     'mo_wgrad_bf16_kk': (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp]),
     'mo_gemm_bf16_256_ex': (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),

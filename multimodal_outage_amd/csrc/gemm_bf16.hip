@@ -32,7 +32,8 @@ __device__ __forceinline__ uint4 gb_load16(const short* base, long row, int ld, 
 template <bool B_KROWS>
 __global__ void __launch_bounds__(256)
 gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ D,
-                 int ldd, int M, int N, int K, int beta, unsigned short* __restrict__ Dbf) {
+                 int ldd, int M, int N, int K, int beta, unsigned short* __restrict__ Dbf,
+                 const float* __restrict__ bias, int relu, const float* __restrict__ mask) {
   __shared__ __attribute__((aligned(16))) short As[2][GB_BM * GB_LDA];
   __shared__ __attribute__((aligned(16))) short Bs[2][B_KROWS ? GB_BK * GB_LDB : GB_BN * GB_LDA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -148,6 +149,9 @@ gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (m >= M) continue;
         float v = acc[i][j][r];
+        if (bias) v += bias[n];
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask && !(mask[(long)m * ldd + n] > 0.f)) v = 0.f;       // ReLU backward: gated by the forward value
         if (D) {
           float* o = D + (long)m * ldd + n;
           if (beta) v += *o;
@@ -160,9 +164,14 @@ gemm_bf16_kernel(const short* __restrict__ A, int lda, const short* __restrict__
     }
 }
 
-extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
-                            int N, int K, int beta, void* D_bf16, void* stream) {
+// fp32-result epilogue options as mo_gemm_bf16_256_ex (+ bias[n], ReLU, ReLU-backward gate).  Four workgroups per CU
+// overlap one tile's stores with the others' k loops: for the head's output-bound products (K = 256 / 512 against
+// 1.6 GB of fp32 result) this kernel beats the 256x256 ring (509 vs 835 us on the skip data gradient, tools/gemm_head.py).
+extern "C" int mo_gemm_bf16_ex(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
+                               int N, int K, int beta, void* D_bf16, const float* bias, int relu, const float* mask,
+                               void* stream) {
   MO_CHECK_ARG(A && B && (D || D_bf16) && M > 0 && N > 0 && K > 0);
+  MO_CHECK_ARG(D || (!bias && !relu && !mask));
   // 16-byte chunk loads: leading dimensions and the contiguous extents must be multiples of 8 elements
   MO_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (K % 8) == 0 && (!b_krows || (N % 8) == 0));
   MO_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
@@ -170,11 +179,15 @@ extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int 
   dim3 grid(8 * ((gm + 1) / 2) * ((gn + 3) / 4));
   if (b_krows)
     hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16, bias, relu, mask);
   else
     hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16);
+                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16, bias, relu, mask);
   return mo_launch_status();
+}
+extern "C" int mo_gemm_bf16(const void* A, int lda, const void* B, int ldb, int b_krows, float* D, int ldd, int M,
+                            int N, int K, int beta, void* D_bf16, void* stream) {
+  return mo_gemm_bf16_ex(A, lda, B, ldb, b_krows, D, ldd, M, N, K, beta, D_bf16, nullptr, 0, nullptr, stream);
 }
 
 // fp32 -> bf16 (round to nearest even; plain cast so that NaNs stay NaNs), 8 elements per thread
@@ -817,5 +830,57 @@ extern "C" int mo_f32_to_bf16_padded(const float* x, int rows, int cols, void* y
   long n = (long)rows * ld_out;
   hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(mo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, cols,
                      (unsigned short*)y, ld_out);
+  return mo_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Skip-path weight gradients of ALL layers as one k-major product (throughput mode): the cropped rows of every layer's
+// gated output g_i that reach the head (graph_wavenet.py:230-236: the last Tf steps) are gathered once into a bf16
+// matrix gcat[G*Tf][32*nl]; dW_all[Cs][32*nl] = dskip^T gcat is then ONE mo_wgrad_bf16_kk launch instead of nl passes over
+// the fp32 dskip (786 MB each at the benchmark size), and mo_skip_wsplit hands layer i its 32 columns.
+// ------------------------------------------------------------------------------------------------------------------
+struct SkipGatherArgs { const float* g[8]; int Tout[8]; int nl; long G; int Tf; };
+__global__ void skip_gather_bf16_kernel(SkipGatherArgs a, uint4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one 8-channel piece
+  const int per_row = 4 * a.nl;
+  const long row = i / per_row;
+  if (row >= a.G * a.Tf) return;
+  const int piece = (int)(i - row * per_row), layer = piece >> 2, c8 = piece & 3;
+  const long grp = row / a.Tf; const int t = (int)(row - grp * a.Tf);
+  const int To = a.Tout[layer];
+  const float4* src = reinterpret_cast<const float4*>(a.g[layer] + ((grp * To + To - a.Tf + t) * 32 + 8 * c8));
+  const float4 x = src[0], y = src[1];
+  const float f[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+  unsigned short h[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { __bf16 tq = (__bf16)f[q]; h[q] = __builtin_bit_cast(unsigned short, tq); }
+  out[i] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16),
+                      h[6] | ((unsigned)h[7] << 16));
+}
+extern "C" int mo_skip_gather_bf16(const float* const* g, const int* Tout, int nl, long G, int Tf, void* out_bf16,
+                                   void* stream) {
+  MO_CHECK_ARG(g && Tout && out_bf16 && nl >= 1 && nl <= 8 && G > 0 && Tf > 0 && ((uintptr_t)out_bf16 % 16) == 0);
+  SkipGatherArgs a; a.nl = nl; a.G = G; a.Tf = Tf;
+  for (int i = 0; i < 8; ++i) { a.g[i] = i < nl ? g[i] : nullptr; a.Tout[i] = i < nl ? Tout[i] : 1; }
+  for (int i = 0; i < nl; ++i) MO_CHECK_ARG(g[i] && Tout[i] >= Tf && ((uintptr_t)g[i] % 16) == 0);
+  const long n = G * Tf * 4L * nl;
+  hipLaunchKernelGGL(skip_gather_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                     (uint4*)out_bf16);
+  return mo_launch_status();
+}
+struct SkipSplitArgs { float* dW[8]; };
+__global__ void skip_wsplit_kernel(const float* __restrict__ all, int Cs, int nl, SkipSplitArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cs * 32 * nl) return;
+  const int co = i / (32 * nl), r = i - co * (32 * nl), layer = r >> 5, c = r & 31;
+  a.dW[layer][co * 32 + c] = all[i];
+}
+extern "C" int mo_skip_wsplit(const float* dW_all, int Cs, int nl, float* const* dW, void* stream) {
+  MO_CHECK_ARG(dW_all && dW && Cs > 0 && nl >= 1 && nl <= 8);
+  SkipSplitArgs a;
+  for (int i = 0; i < 8; ++i) a.dW[i] = i < nl ? dW[i] : nullptr;
+  for (int i = 0; i < nl; ++i) MO_CHECK_ARG(dW[i]);
+  hipLaunchKernelGGL(skip_wsplit_kernel, dim3(mo_cdiv((long)Cs * 32 * nl, 256)), dim3(256), 0, (hipStream_t)stream, dW_all,
+                     Cs, nl, a);
   return mo_launch_status();
 }

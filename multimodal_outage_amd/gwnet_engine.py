@@ -8,6 +8,7 @@ product is a row operation on [N][B*T*32] and every channel contraction a GEMM o
 BatchNorm of layer i is never materialised: the kernels that consume x_{i+1} = BN(h_i) apply the
 folded affine (scale, shift) on load (tcn / residual), and the backward recomputes xhat from h_i.
 """
+import ctypes as _C
 import numpy as np
 import os
 
@@ -411,7 +412,6 @@ class GwnetFunction(torch.autograd.Function):
 
         # skip path (graph_wavenet.py:230-236): only the last Tf steps of every layer's skip conv reach the head,
         # so all of them are ONE contraction over the concatenated channels; skip is written once
-        import ctypes as _C
         P_f = G * Tf
         # throughput mode: the head's two real contractions (end_conv_1 forward / data gradient) run as bf16 ring-GEMM
         # launches with bias+ReLU / ReLU-gate epilogues; skip is then stored post-ReLU (all its consumers apply ReLU)
@@ -431,7 +431,8 @@ class GwnetFunction(torch.autograd.Function):
             W1 = p['end_conv_1.weight']
             W1_bf = torch.empty((cfg.Ce, cfg.Cs), device=dev, dtype=torch.bfloat16)
             L.call('mo_f32_to_bf16', L.ptr(W1), L.ptr(W1_bf), W1.numel(), st)
-            L.call('mo_gemm_bf16_256_ex', L.ptr(skip_bf), cfg.Cs, cfg.Cs, L.ptr(W1_bf), cfg.Cs, 0, L.ptr(r1), cfg.Ce,
+            # output-bound (K = Cs against a P_f x Ce fp32 result): the 128x128 kernel, four workgroups per CU
+            L.call('mo_gemm_bf16_ex', L.ptr(skip_bf), cfg.Cs, L.ptr(W1_bf), cfg.Cs, 0, L.ptr(r1), cfg.Ce,
                    P_f, cfg.Ce, cfg.Cs, 0, None, L.ptr(p['end_conv_1.bias']), 1, None, st)
         else:
             L.call('mo_conv1x1_fwd', L.ptr(skip), cfg.Cs, 0, 0, 0, 1, L.ptr(p['end_conv_1.weight']),
@@ -512,12 +513,14 @@ class GwnetFunction(torch.autograd.Function):
                                     L.ptr(gW1), L.ptr(gb1), L.ptr(ws_for(cfg.Ce, cfg.Cs, P_f)), L.stream()),
                      reads=(da1,))
         dskip = _e(P_f, cfg.Cs, dev)
+        skip_w_done = False
+        gWs_all = None
         dg_skip = None        # throughput mode: [P_f][32*L] data gradients of all layers' skip convs, one product
         if ctx.W1_bf is not None:
             # dskip = (da1 @ W1) gated by skip > 0: W1 (Ce, Cs) row-major is the [K][N] operand as it lies
             fuse_skip = cfg.Cs % 32 == 0 and (32 * cfg.L) % 8 == 0
             dskip_bf = torch.empty((P_f, cfg.Cs), device=dev, dtype=torch.bfloat16) if fuse_skip else None
-            L.call('mo_gemm_bf16_256_ex', L.ptr(da1_bf), cfg.Ce, cfg.Ce, L.ptr(ctx.W1_bf), cfg.Cs, 1, L.ptr(dskip), cfg.Cs,
+            L.call('mo_gemm_bf16_ex', L.ptr(da1_bf), cfg.Ce, L.ptr(ctx.W1_bf), cfg.Cs, 1, L.ptr(dskip), cfg.Cs,
                    P_f, cfg.Cs, cfg.Ce, 0, L.ptr(dskip_bf), None, 0, L.ptr(skip), st)
             if fuse_skip:
                 # dg_i[crop] += dskip @ Ws_i for every layer i at once: Ws_i (Cs, 32) side by side is the [K][N] operand
@@ -525,8 +528,25 @@ class GwnetFunction(torch.autograd.Function):
                 Wcat_bf = torch.empty((cfg.Cs, 32 * cfg.L), device=dev, dtype=torch.bfloat16)
                 L.call('mo_f32_to_bf16', L.ptr(Wcat), L.ptr(Wcat_bf), Wcat.numel(), st)
                 dg_skip = _e(P_f, 32 * cfg.L, dev)
-                L.call('mo_gemm_bf16_256', L.ptr(dskip_bf), cfg.Cs, cfg.Cs, L.ptr(Wcat_bf), 32 * cfg.L, 1,
+                L.call('mo_gemm_bf16', L.ptr(dskip_bf), cfg.Cs, L.ptr(Wcat_bf), 32 * cfg.L, 1,
                        L.ptr(dg_skip), 32 * cfg.L, P_f, 32 * cfg.L, cfg.Cs, 0, None, st)
+                if P_f % 32 == 0 and cfg.Cs % 8 == 0:
+                    # ... and their weight gradients one k-major product over the gathered crops of every layer's g
+                    gWs_all = [gbuf(f'skip_convs.{i}.weight', p[f'skip_convs.{i}.weight']) for i in range(cfg.L)]
+
+                    def _skip_w(dskip_bf=dskip_bf, gWs_all=gWs_all):
+                        gcat = torch.empty((P_f, 32 * cfg.L), device=dev, dtype=torch.bfloat16)
+                        touts = (_C.c_int * cfg.L)(*[ctx.layers[i]['Tout'] for i in range(cfg.L)])
+                        L.call('mo_skip_gather_bf16', L.ptr_array([ctx.layers[i]['g'] for i in range(cfg.L)]), touts, cfg.L,
+                               G, Tf, L.ptr(gcat), L.stream())
+                        dW_all = _e(cfg.Cs, 32 * cfg.L, dev)
+                        wsk = torch.empty(lib.mo_wgrad_bf16_kk_ws_floats(cfg.Cs, 32 * cfg.L, P_f), device=dev,
+                                          dtype=torch.float32)
+                        L.call('mo_wgrad_bf16_kk', L.ptr(dskip_bf), cfg.Cs, L.ptr(gcat), 32 * cfg.L, P_f, cfg.Cs, 32 * cfg.L,
+                               L.ptr(dW_all), L.ptr(wsk), L.stream())
+                        L.call('mo_skip_wsplit', L.ptr(dW_all), cfg.Cs, cfg.L, L.ptr_array(gWs_all), L.stream())
+                    lane.run(_skip_w, reads=(dskip_bf,))
+                    skip_w_done = True
         else:
             L.call('mo_conv1x1_bwd_data', L.ptr(da1), cfg.Ce, P_f, L.ptr(p['end_conv_1.weight']), cfg.Cs,
                    L.ptr(dskip), 0, 0, 0, L.ptr(skip), 0, st)
@@ -644,10 +664,13 @@ class GwnetFunction(torch.autograd.Function):
             else:
                 L.call('mo_conv1x1_bwd_data', L.ptr(dskip), cfg.Cs, P_f, L.ptr(Ws), 32, L.ptr(dg), Tf, Tout,
                        Tout - Tf, None, beta, st)
-            gWs = gbuf(f'skip_convs.{i}.weight', Ws)
-            lane.run(lambda g=g, gWs=gWs, Tout=Tout: L.call(
-                'mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
-                L.ptr(gWs), None, L.ptr(ws_for(cfg.Cs, 32, P_f)), L.stream()), reads=(dskip,))
+            if skip_w_done:
+                gWs = gWs_all[i]
+            else:
+                gWs = gbuf(f'skip_convs.{i}.weight', Ws)
+                lane.run(lambda g=g, gWs=gWs, Tout=Tout: L.call(
+                    'mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
+                    L.ptr(gWs), None, L.ptr(ws_for(cfg.Cs, 32, P_f)), L.stream()), reads=(dskip,))
             grads[f'skip_convs.{i}.weight'] = gWs
             sb = gout.get(f'skip_convs.{i}.bias')
             if sb is not None:

@@ -22,7 +22,8 @@ cases = {
     'end_conv_1 dgrad (relu gate, fp32 + bf16 out)': lambda: L.call('mo_gemm_bf16_256_ex', L.ptr(da1_bf), Ce, Ce, L.ptr(W1_bf), Cs, 1, L.ptr(dskip), Cs, P, Cs, Ce, 0, L.ptr(dskip_bf), None, 0, L.ptr(skip), st),
     'skip dgrad all layers (fp32 out)': lambda: L.call('mo_gemm_bf16_256', L.ptr(dskip_bf), Cs, Cs, L.ptr(Wcat_bf), 256, 1, L.ptr(dg_skip), 256, P, 256, Cs, 0, None, st),
 }
-bytes_ = {'end_conv_1 fwd (bias+relu, fp32 out)': P * (Cs * 2 + Ce * 4), 'end_conv_1 dgrad (relu gate, fp32 + bf16 out)': P * (Ce * 2 + Cs * 4 + Cs * 6),
+cases['skip dgrad all layers, 128x128 kernel'] = lambda: L.call('mo_gemm_bf16', L.ptr(dskip_bf), Cs, L.ptr(Wcat_bf), 256, 1, L.ptr(dg_skip), 256, P, 256, Cs, 0, None, st)
+bytes_ = {'skip dgrad all layers, 128x128 kernel': P * (Cs * 2 + 256 * 4), 'end_conv_1 fwd (bias+relu, fp32 out)': P * (Cs * 2 + Ce * 4), 'end_conv_1 dgrad (relu gate, fp32 + bf16 out)': P * (Ce * 2 + Cs * 4 + Cs * 6),
           'skip dgrad all layers (fp32 out)': P * (Cs * 2 + 256 * 4)}
 for name, fn in cases.items():
     for _ in range(3): fn()
