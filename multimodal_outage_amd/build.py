@@ -44,8 +44,17 @@ def _stale(src):
 def build(force=False, verbose=True):
     """hipcc --offload-arch=gfx950 -c per source, then -shared -> multimodal_outage_amd/libmo_hip.so"""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    os.makedirs(OBJ, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and os.path.exists(LIB):
+        # the library is newer than every source and header: nothing to do, even where the per-source objects are absent
+        # (they are build scratch and do not travel to the GPU box; the .so does)
+        t = os.path.getmtime(LIB)
+        deps = set()
+        for s_ in srcs:
+            deps |= _deps(os.path.join(CSRC, s_))
+        if all(os.path.getmtime(d) <= t for d in deps):
+            return LIB
+    os.makedirs(OBJ, exist_ok=True)
     todo = [s for s in srcs if force or _stale(s)]
     flags = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-I', os.path.join(ROOT, 'include'),
              '-I', '/opt/rocm/include']
