@@ -86,6 +86,18 @@ def alg_bytes(dtype):
     return block * N_NODES, step * N_NODES
 
 
+def unet_pmc_traffic(batch, horizon, cin, size):
+    """HBM bytes per step of the whole UNet leg (every kernel: conv stack, FC bottleneck and its Adam, Graph WaveNet, loss)
+    from the committed FETCH_SIZE / WRITE_SIZE passes of tools/bench_unet.py (tools/unet_pmc_summary.py); None when the
+    leg's shape is not the profiled one."""
+    if (batch, horizon, cin, size) != (1, 2, 13, 256):
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r02_unet_c3_pmc_traffic.json')))['bytes_per_step']
+    except Exception:
+        return None
+
+
 def host_cores():
     """Cores this process may really use: cgroup CPU quota if set, else affinity, capped at the
     16-core share of a one-GPU box (oversubscribing the quota makes the CPU leg crawl)."""
@@ -235,7 +247,8 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
     roof = {"bound": "hbm", "kernel": "UNet conv stack (all kernels of the Modified_UNET step)",
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBPS, 4),
             "algorithmic_MB_per_tile_fwd": round(UNET_BYTES_FWD_PER_TILE * scale / 1e6, 2),
-            "vector_TFLOPs": round(3 * UNET_FLOP_FWD_PER_TILE * scale * tps / world / 1e12, 2), "traffic": None}
+            "vector_TFLOPs": round(3 * UNET_FLOP_FWD_PER_TILE * scale * tps / world / 1e12, 2),
+            "traffic": unet_pmc_traffic(batch, horizon, cin, size)}
     return {"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(tps, 1), "unit": "tiles/s", "roofline": roof,
             "ms_per_step": round(dt / steps * 1e3, 2), "tiles_per_step_per_gpu": tiles, "steps": steps, "warmup": warmup,
             "trace": trace, "dtype": ("bf16 activation storage at >= 64x64, fp32 arithmetic" if act_dtype == 'bf16' else "f32"),
