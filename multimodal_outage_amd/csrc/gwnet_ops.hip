@@ -343,6 +343,7 @@ extern "C" int mo_nbtc_to_nchw(const float* y, float* x, int B, int C, int N, in
 // ------------------------------------------------------------------------------------------------
 // 1x1 conv / Linear
 // ------------------------------------------------------------------------------------------------
+static int linear_bm(long P);
 extern "C" int mo_conv1x1_fwd(const float* in, int Ci, int To, int Ti, int off, int in_relu, const float* W,
                               const float* b, int Co, float* out, long P_out, int out_relu, int beta,
                               void* stream) {
@@ -354,6 +355,8 @@ extern "C" int mo_conv1x1_fwd(const float* in, int Ci, int To, int Ti, int off, 
   E.bias = b; E.relu = out_relu; E.beta = beta;
   if (Co <= 32)
     return launch<128, 32, 32, 4, 1, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P_out, Co, 1, ST(stream));
+  if (linear_bm(P_out) == 32)      // few rows (the 67-county Graph WaveNet inside Modified_UNET, the fc layers): 32-row tiles
+    return launch<32, 128, 32, 1, 4, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P_out, Co, 1, ST(stream));
   return launch<128, 128, 16, 2, 2, MO_XROWS, MO_XROWS, MO_EPI_STORE>(A, Bo, E, P_out, Co, 1, ST(stream));
 }
 
@@ -441,6 +444,8 @@ extern "C" int mo_conv1x1_bwd_data(const float* dout, int Co, long P, const floa
   E.oTo = oTo; E.oTi = oTi; E.ooff = ooff; E.mask = mask; E.ldmask = Ci; E.beta = beta;
   if (Ci <= 32)
     return launch<128, 32, 32, 4, 1, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, 1, ST(stream));
+  if (linear_bm(P) == 32)
+    return launch<32, 128, 32, 1, 4, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, 1, ST(stream));
   return launch<128, 128, 16, 2, 2, MO_XROWS, MO_KROWS, MO_EPI_STORE>(A, Bo, E, P, Ci, 1, ST(stream));
 }
 

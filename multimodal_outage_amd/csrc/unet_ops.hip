@@ -613,23 +613,6 @@ extern "C" int mo_maxpool2_bwd(const float* x, long istride, int C, long n_img, 
 //   dz = [a>0] * ( da[img][c][pix] + (pix is the first arg-max of its 2x2 window ? dp[img][c][pix/2] : 0) )
 //   dy = gamma*rstd*(dz - mean_g(dz) - xhat*mean_g(dz*xhat))
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float unet_dz(const float* __restrict__ yp, int H, int W, int yy, int x, float s, float t,
-                                         const float* __restrict__ da_p, const float* __restrict__ dp_p) {
-  const float a = yp[(long)yy * W + x] * s + t;
-  if (!(a > 0.f)) return 0.f;
-  float d = da_p ? da_p[(long)yy * W + x] : 0.f;
-  if (dp_p) {
-    const int y0 = yy & ~1, x0 = x & ~1;
-    const float* q = yp + (long)y0 * W + x0;
-    float v[4] = {q[0] * s + t, q[1] * s + t, q[W] * s + t, q[W + 1] * s + t};
-    int am = 0; float mx = v[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) if (v[k] > mx) { mx = v[k]; am = k; }
-    const int me = (yy - y0) * 2 + (x - x0);
-    if (me == am) d += dp_p[(long)(yy >> 1) * (W >> 1) + (x >> 1)];
-  }
-  return d;
-}
 // dz of the 4 pixels (yy, 4q..4q+3) of one channel plane: 16-byte loads; with max-pool routing the partner row of the
 // 2x2 windows is read as well (the first maximum in scan order takes the pooled gradient, as F.max_pool2d does)
 struct UaFlags { int y, da, dp, dy; };       // bf16 storage of the four tensors of the activation backward
