@@ -21,10 +21,12 @@
 #define MO_BF_DP 16
 static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 = previous VALU / split-K weight gradients
 static int mo_opt_no_mfma_conv = 0;      // 1 = deep-level convs on the im2col tile engine / VALU direct kernel as before
+static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
 extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!name) return MO_EINVAL;
   if (!strcmp(name, "no_mfma_wgrad")) { mo_opt_no_mfma_wgrad = value; return MO_OK; }
   if (!strcmp(name, "no_mfma_conv")) { mo_opt_no_mfma_conv = value; return MO_OK; }
+  if (!strcmp(name, "ux_min_co")) { mo_opt_ux_min_co = value; return MO_OK; }
   return MO_EINVAL;
 }
 
@@ -162,7 +164,7 @@ static int ux_tw(int Co, long n_img, int H, int Wd) {
   if ((Wd % 16) == 0 && (H % 16) == 0) return 16;
   return 0;
 }
-static bool ux_preferred(int Co, int H, int Wd) { return Co > 16 || H < 32 || Wd < 32; }
+static bool ux_preferred(int Co, int H, int Wd) { return Co >= mo_opt_ux_min_co || H < 32 || Wd < 32; }
 extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd) {
   const int tw = ux_tw(Co, n_img, H, Wd);
   if (tw && ux_preferred(Co, H, Wd)) return (Wd / tw) * (H / (256 / tw));

@@ -19,10 +19,14 @@ def main():
     ap.add_argument('--cin', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--opt', action='append', default=[], help='name=value for mo_unet_set_option (A/B switches)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16', help="activation storage (Modified_UNET.act_dtype)")
     a = ap.parse_args()
     import multimodal_outage_amd._lib as L
     L.load()
+    for o in a.opt:
+        k, v = o.split('=')
+        L.call('mo_unet_set_option', k.encode(), int(v))
     from multimodal_outage_amd.models.unet import Modified_UNET
     from multimodal_outage_amd.lit import mse_and_metrics
     from multimodal_outage_amd.trainer import FlatTrainer
