@@ -263,7 +263,7 @@ int mo_convt2x2_bwd_data(const float* dout, long dostride, int Co, const float* 
                          int Wd, float* din, long distride, void* stream);
 int mo_convt2x2_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride, int Ci,
                            const float* sc, const float* sh, int relu, int gsize, long n_img, int H, int Wd,
-                           float* dW, float* ws, void* stream);
+                           float* dW, float* db /* bias gradient, may be NULL */, float* ws, void* stream);
 /* BatchNorm2d statistics (unet.py:45,48): stats[img][c] = (sum, sumsq) over HW */
 int mo_nchw_stats(const float* y, long istride, int C, long n_img, int HW, float* stats, void* stream);
 /* per-group finalize: scale/shift/mean/rstd [G][C]; running stats receive G sequential momentum updates

@@ -76,7 +76,7 @@ SIGNATURES = {
     'mo_nchw_conv1x1_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
     'mo_convt2x2_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, i32, vp, i64, vp]),
     'mo_convt2x2_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, i32, vp, i64, vp]),
-    'mo_convt2x2_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp]),
+    'mo_convt2x2_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp]),
     'mo_nchw_stats': (i32, [vp, i64, i32, i64, i32, vp, vp]),
     'mo_group_bn_finalize': (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     'mo_unet_act': (i32, [vp, i64, i32, i64, i32, i32, vp, vp, i32, i32, vp, i64, i32, vp]),

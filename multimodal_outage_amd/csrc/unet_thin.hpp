@@ -126,3 +126,193 @@ __global__ __launch_bounds__(256) void ut_wgrad1x1_kernel(UtWgArgs a) {
     row[i] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k=2, s=2) of the thin Up blocks (unet.py:71: up3 16->8 at 64^2 -> 128^2, up4 8->4 at 128^2 -> 256^2):
+// every input pixel feeds exactly one 2x2 output patch, so the layer is a 1x1 conv with 4*Co outputs and a scatter --
+// a pure stream.  A thread owns 4 neighbouring input pixels of a row, i.e. 8 neighbouring output pixels of two rows.
+//   out[co][2y+ky][2x+kx] = b[co] + sum_ci W[ci][co][ky][kx] * act(in[ci][y][x])
+// ------------------------------------------------------------------------------------------------
+struct UtTArgs {
+  const float* in; long is; int Ci;                      // input view (H x W), optional folded affine + ReLU, fp32 | bf16
+  const float* sc; const float* sh; int relu, gsize, bfi;
+  const float* W; const float* b;                        // (Ci, Co, 2, 2), (Co)
+  float* out; long os; int Co;                           // fp32, (2H x 2W); for the data gradient: `out` is din (H x W)
+  const float* dout; long dos;                           // data / weight gradient: gradient w.r.t. out
+  float* slab;                                           // weight gradient: [rows][Ci*Co*4 + Co]
+  long n_img; int H, Wd, img_per_wg, cic;
+};
+template <int CO>
+__global__ __launch_bounds__(256) void ut_convt_fwd_kernel(UtTArgs a) {
+  __shared__ float wsm[16][CO * 4 + 1];
+  __shared__ float bsm[CO];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.Ci * CO * 4; i += 256) {
+    const int ci = i / (CO * 4), r = i - ci * (CO * 4), co = r >> 2;
+    wsm[ci][r] = co < a.Co ? a.W[((long)ci * a.Co + co) * 4 + (r & 3)] : 0.f;
+  }
+  if (tid < CO) bsm[tid] = tid < a.Co ? a.b[tid] : 0.f;
+  __syncthreads();
+  const long img = blockIdx.y;
+  const long grp = img / a.gsize;
+  const int Q = a.Wd >> 2, W2 = 2 * a.Wd;
+  for (int q = blockIdx.x * 256 + tid; q < a.H * Q; q += gridDim.x * 256) {
+    const int y = q / Q, x = (q - y * Q) * 4;
+    float acc[CO][4][4];                                  // [co][ky*2+kx][pixel]
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[co][k][p] = bsm[co];
+    for (int ci = 0; ci < a.Ci; ++ci) {
+      float4 v = ua_ld4(a.in, img * a.is + ((long)ci * a.H + y) * a.Wd + x, a.bfi);
+      if (a.sc) {
+        const float s = a.sc[grp * a.Ci + ci], t = a.sh[grp * a.Ci + ci];
+        v.x = v.x * s + t; v.y = v.y * s + t; v.z = v.z * s + t; v.w = v.w * s + t;
+      }
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float w = wsm[ci][co * 4 + k];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[co][k][p] += w * vv[p];
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+      if (co < a.Co)
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky) {
+          float* o = a.out + img * a.os + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x;
+          *reinterpret_cast<float4*>(o) = make_float4(acc[co][2 * ky][0], acc[co][2 * ky + 1][0], acc[co][2 * ky][1], acc[co][2 * ky + 1][1]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(acc[co][2 * ky][2], acc[co][2 * ky + 1][2], acc[co][2 * ky][3], acc[co][2 * ky + 1][3]);
+        }
+  }
+}
+// din[ci][y][x] = sum_{co,ky,kx} W[ci][co][ky][kx] * dout[co][2y+ky][2x+kx]
+template <int CI>
+__global__ __launch_bounds__(256) void ut_convt_bwd_data_kernel(UtTArgs a) {
+  __shared__ float wsm[8 * 4][CI + 1];                    // [co*4 + k][ci]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.Co * 4 * CI; i += 256) {
+    const int r = i / CI, ci = i - r * CI;
+    wsm[r][ci] = ci < a.Ci ? a.W[((long)ci * a.Co + (r >> 2)) * 4 + (r & 3)] : 0.f;
+  }
+  __syncthreads();
+  const long img = blockIdx.y;
+  const int Q = a.Wd >> 2, W2 = 2 * a.Wd;
+  for (int q = blockIdx.x * 256 + tid; q < a.H * Q; q += gridDim.x * 256) {
+    const int y = q / Q, x = (q - y * Q) * 4;
+    float acc[CI][4];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[ci][p] = 0.f;
+    for (int co = 0; co < a.Co; ++co)
+#pragma unroll
+      for (int ky = 0; ky < 2; ++ky) {
+        const float* d = a.dout + img * a.dos + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x;
+        const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + 4);
+        const float e[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};      // (pixel p, kx) = e[2p + kx]
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci) {
+            const float w = wsm[co * 4 + ky * 2 + kx][ci];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[ci][p] += w * e[2 * p + kx];
+          }
+      }
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+      if (ci < a.Ci)
+        *reinterpret_cast<float4*>(a.out + img * a.os + ((long)ci * a.H + y) * a.Wd + x) =
+            make_float4(acc[ci][0], acc[ci][1], acc[ci][2], acc[ci][3]);
+  }
+}
+// dW[ci][co][ky][kx] = sum act(in)[ci][y][x] * dout[co][2y+ky][2x+kx];  db[co] = sum dout[co] (chunk 0 only).
+// grid = (pixel blocks, image ranges, chunks of 4 input channels); slab rows [Ci*Co*4 + Co] as for ut_wgrad1x1_kernel.
+template <int CO>
+__global__ __launch_bounds__(256) void ut_convt_wgrad_kernel(UtTArgs a) {
+  __shared__ float red[4][4 * CO * 4 + CO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci0 = blockIdx.z * 4;
+  float acc[4][CO * 4], accb[CO];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < CO * 4; ++r) acc[c][r] = 0.f;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) accb[co] = 0.f;
+  const long img0 = (long)blockIdx.y * a.img_per_wg, img1 = min(img0 + a.img_per_wg, a.n_img);
+  const int Q = a.Wd >> 2, W2 = 2 * a.Wd;
+  for (long img = img0; img < img1; ++img) {
+    const long grp = img / a.gsize;
+    for (int q = blockIdx.x * 256 + tid; q < a.H * Q; q += gridDim.x * 256) {
+      const int y = q / Q, x = (q - y * Q) * 4;
+      float xv[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ci = ci0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci < a.Ci) {
+          v = ua_ld4(a.in, img * a.is + ((long)ci * a.H + y) * a.Wd + x, a.bfi);
+          if (a.sc) {
+            const float s = a.sc[grp * a.Ci + ci], t = a.sh[grp * a.Ci + ci];
+            v.x = v.x * s + t; v.y = v.y * s + t; v.z = v.z * s + t; v.w = v.w * s + t;
+          }
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        xv[c][0] = v.x; xv[c][1] = v.y; xv[c][2] = v.z; xv[c][3] = v.w;
+      }
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+        if (co < a.Co)
+#pragma unroll
+          for (int ky = 0; ky < 2; ++ky) {
+            const float* d = a.dout + img * a.dos + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x;
+            const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + 4);
+            const float e[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            accb[co] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                acc[c][co * 4 + ky * 2 + kx] += xv[c][0] * e[kx] + xv[c][1] * e[2 + kx] + xv[c][2] * e[4 + kx] + xv[c][3] * e[6 + kx];
+          }
+    }
+  }
+  constexpr int NR = 4 * CO * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < CO * 4; ++r) {
+      float v = acc[c][r];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wave][c * CO * 4 + r] = v;
+    }
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    float v = accb[co];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wave][NR + co] = v;
+  }
+  __syncthreads();
+  const int nrow = a.Ci * a.Co * 4 + a.Co;
+  float* row = a.slab + ((long)blockIdx.y * gridDim.x + blockIdx.x) * nrow;
+  for (int i = tid; i < NR + CO; i += 256) {
+    const float s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    if (i < NR) {
+      const int c = i / (CO * 4), r = i - c * (CO * 4), co = r >> 2;
+      if (ci0 + c < a.Ci && co < a.Co) row[((long)(ci0 + c) * a.Co + co) * 4 + (r & 3)] = s;
+    } else if (blockIdx.z == 0 && i - NR < a.Co) {
+      row[(long)a.Ci * a.Co * 4 + (i - NR)] = s;
+    }
+  }
+}

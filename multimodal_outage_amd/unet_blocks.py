@@ -112,12 +112,11 @@ class UpFn(torch.autograd.Function):
         dus = dcat.stride(0)
         Wt = p[cfg.pre + '.up.weight']
         dWt = grads.buf(cfg.pre + '.up.weight', Wt.shape)
-        ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Ci, 4 * C0, n * H * W), device=dev, dtype=torch.float32)
-        L.call('mo_convt2x2_bwd_weight', du.data_ptr(), dus, C0, L.ptr(ctx.x1), Ci * H * W, Ci, None, None, 0, gs, n, H, W,
-               L.ptr(dWt), L.ptr(ws), st)
+        ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Ci, 4 * C0, n * H * W), n * C0 * 2), device=dev,
+                         dtype=torch.float32)
         dbt = grads.buf(cfg.pre + '.up.bias', (C0,))
-        wsb = _empty(n * C0 * 2, dev=dev)
-        L.call('mo_nchw_channel_sum', du.data_ptr(), dus, C0, n, 4 * H * W, L.ptr(dbt), L.ptr(wsb), st)
+        L.call('mo_convt2x2_bwd_weight', du.data_ptr(), dus, C0, L.ptr(ctx.x1), Ci * H * W, Ci, None, None, 0, gs, n, H, W,
+               L.ptr(dWt), L.ptr(dbt), L.ptr(ws), st)
         dx1 = _empty(n, Ci, H, W, dev=dev)
         L.call('mo_convt2x2_bwd_data', du.data_ptr(), dus, C0, L.ptr(Wt), Ci, n, H, W, L.ptr(dx1), Ci * H * W, st)
         return (None, dx1, dx2) + grads.result(cfg.names)
@@ -282,12 +281,11 @@ class ExpansionFn(torch.autograd.Function):
             dus = dcat.stride(0)
             Wt = p[f'up{k}.up.weight']
             dWt = grads.buf(f'up{k}.up.weight', Wt.shape)
-            wsu = torch.empty(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), device=dev, dtype=torch.float32)
-            L.call('mo_convt2x2_bwd_weight', du.data_ptr(), dus, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
-                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(wsu), st)
+            wsu = torch.empty(max(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), n * C0 * 2), device=dev,
+                              dtype=torch.float32)
             dbt = grads.buf(f'up{k}.up.bias', (C0,))
-            wsb = _empty(n * C0 * 2, dev=dev)
-            L.call('mo_nchw_channel_sum', du.data_ptr(), dus, C0, n, 4 * H * H, L.ptr(dbt), L.ptr(wsb), st)
+            L.call('mo_convt2x2_bwd_weight', du.data_ptr(), dus, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
+                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(dbt), L.ptr(wsu), st)
             da = _empty(n, ci, H, H, dev=dev)
             L.call('mo_convt2x2_bwd_data', du.data_ptr(), dus, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
         return (None, da, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(cfg.names)

@@ -385,12 +385,11 @@ class UnetDecodeFn(torch.autograd.Function):
             du_stride = dcat.stride(0)
             Wt = p[f'expansion.up{k}.up.weight']
             dWt = grads.buf(f'expansion.up{k}.up.weight', Wt.shape)
-            wsu = torch.empty(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), device=dev, dtype=torch.float32)
-            L.call('mo_convt2x2_bwd_weight', du.data_ptr(), du_stride, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
-                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(wsu), st)
+            wsu = torch.empty(max(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), n * C0 * 2), device=dev,
+                              dtype=torch.float32)
             dbt = grads.buf(f'expansion.up{k}.up.bias', (C0,))
-            wsb = _empty(n * C0 * 2, dev=dev)
-            L.call('mo_nchw_channel_sum', du.data_ptr(), du_stride, C0, n, 4 * H * H, L.ptr(dbt), L.ptr(wsb), st)
+            L.call('mo_convt2x2_bwd_weight', du.data_ptr(), du_stride, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
+                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(dbt), L.ptr(wsu), st)
             da = _empty(n, ci, H, H, dev=dev)
             L.call('mo_convt2x2_bwd_data', du.data_ptr(), du_stride, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
         dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads)

@@ -143,7 +143,10 @@ def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da, bf):
     close(dbet, beta.grad, what='dbeta')
 
 
-@pytest.mark.parametrize('n,gs,Ci,Co,H,W,act', [(4, 2, 64, 32, 8, 8, False), (4, 2, 8, 4, 16, 16, True), (2, 1, 16, 8, 4, 8, True)])
+@pytest.mark.parametrize('n,gs,Ci,Co,H,W,act', [(4, 2, 64, 32, 8, 8, False), (4, 2, 8, 4, 16, 16, True), (2, 1, 16, 8, 4, 8, True),
+                                                # streaming kernels of the thin Up blocks: ragged channel chunks, many images per workgroup
+                                                (6, 2, 8, 4, 64, 64, True), (3, 1, 16, 8, 32, 48, True), (2, 2, 6, 3, 8, 20, False),
+                                                (70, 2, 8, 4, 32, 32, True), (2, 1, 10, 5, 16, 16, True)])
 def test_convt2x2_fwd_bwd(L, n, gs, Ci, Co, H, W, act):
     lib = L.load()
     G = n // gs
@@ -168,14 +171,16 @@ def test_convt2x2_fwd_bwd(L, n, gs, Ci, Co, H, W, act):
            Ci * H * W, L.stream())
     close(din, a.grad, what='convT bwd data')
     dW = torch.empty(Ci, Co, 2, 2, device='cuda')
-    ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Ci, 4 * Co, n * H * W), device='cuda')
-    L.call('mo_convt2x2_bwd_weight', L.ptr(dd), Co * 4 * H * W, Co, L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd),
-           1 if act else 0, gs, n, H, W, L.ptr(dW), L.ptr(ws), L.stream())
-    close(dW, Wt.grad, what='convT dW')
     db = torch.empty(Co, device='cuda')
-    ws2 = torch.empty(n * Co * 2, device='cuda')
-    L.call('mo_nchw_channel_sum', L.ptr(dd), Co * 4 * H * W, Co, n, 4 * H * W, L.ptr(db), L.ptr(ws2), L.stream())
+    ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Ci, 4 * Co, n * H * W), n * Co * 2), device='cuda')
+    L.call('mo_convt2x2_bwd_weight', L.ptr(dd), Co * 4 * H * W, Co, L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd),
+           1 if act else 0, gs, n, H, W, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+    close(dW, Wt.grad, what='convT dW')
     close(db, b.grad, what='convT db')
+    db2 = torch.empty(Co, device='cuda')
+    ws2 = torch.empty(n * Co * 2, device='cuda')
+    L.call('mo_nchw_channel_sum', L.ptr(dd), Co * 4 * H * W, Co, n, 4 * H * W, L.ptr(db2), L.ptr(ws2), L.stream())
+    close(db2, b.grad, what='channel sum')
 
 
 @pytest.mark.parametrize('n,gs,Ci,Co,HW', [(4, 2, 4, 1, 256), (2, 1, 4, 3, 64), (6, 2, 4, 13, 64 * 64), (4, 2, 8, 8, 1028),
