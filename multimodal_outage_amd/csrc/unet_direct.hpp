@@ -288,33 +288,38 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
 //   A[m][k] = act(in)[ci][y + ky - 1][x0 + k + kx - 1]   (a gather from the LDS halo tile: one ds_read_b32 per lane),
 //   B[k][j] = dy[co][y][x0 + k]                          (LDS, planes padded so that the 16 channels hit 16 banks),
 // so a wave accumulates all Co x 16 input channels x 9 taps in 4*MB*NB registers over every pixel it visits and the
-// workgroup's partial result is folded once, at the end of its image range.  One workgroup = one 8 x 64 tile
+// workgroup's partial result is folded once, at the end of its image range.  One workgroup = one 512-pixel tile
 // position x a range of images x one chunk of 16 input channels; slab rows as for ud_wgrad3x3_kernel.
 // ------------------------------------------------------------------------------------------------
 typedef float uw_f32x4 __attribute__((ext_vector_type(4)));
-#define UW_TH 8
-#define UW_TW 64
-#define UW_LDT 72                     // halo row: col 3 = x0-1, cols 4..67 = interior, col 68 = x0+64
-#define UW_PS (10 * UW_LDT + 8)       // halo plane stride (+8: planes 24 banks apart, rows 8)
+// tiles of 512 pixels: 8 x 64, for narrower images 16 x 32 / 32 x 16 (template parameter TW)
 #define UW_CIC 16                     // input channels per workgroup
-#define UW_DPS (UW_TH * UW_TW + 4)    // dy plane stride (+4: channel j of the B fragment lands on bank 4j + k)
+template <int TW> struct UwGeo {
+  static constexpr int TH = 512 / TW;
+  static constexpr int LDT = TW + 8;                // halo row: col 3 = x0-1, cols 4.. = interior, col TW+4 = x0+TW
+  static constexpr int PS = (TH + 2) * LDT + 8;     // halo plane stride (+8: planes spread over the banks)
+  static constexpr int DPS = TH * TW + 4;           // dy plane stride (+4: channel j of the B fragment lands on bank 4j + k)
+};
 
 // dynamic LDS: max(cmax*UW_PS + Co*UW_DPS, 4*NB*MB*256) floats, cmax = min(Ci, UW_CIC) -- sized by the layer, so that
 // the thin layers (20 KB) put 4..8 workgroups on a CU and hide their own staging latency
+template <int TW>
 static inline size_t uw_lds_bytes(int Ci, int Co, int NB, int MB) {
   const int cmax = Ci < UW_CIC ? Ci : UW_CIC;
-  size_t a = (size_t)cmax * UW_PS + (size_t)Co * UW_DPS, b = (size_t)4 * NB * MB * 256;
+  size_t a = (size_t)cmax * UwGeo<TW>::PS + (size_t)Co * UwGeo<TW>::DPS, b = (size_t)4 * NB * MB * 256;
   return (a > b ? a : b) * sizeof(float);
 }
-template <int NB, int MB>             // Co <= 16*NB, chunk channels * 9 <= 16*MB
+template <int NB, int MB, int TW = 64>     // Co <= 16*NB, chunk channels * 9 <= 16*MB, tile (512/TW) x TW
 __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
+  constexpr int UW_TH_ = UwGeo<TW>::TH, UW_LDT = UwGeo<TW>::LDT, UW_PS = UwGeo<TW>::PS, UW_DPS = UwGeo<TW>::DPS;
+  constexpr int QPR = TW / 4;                                        // pixel quads per tile row
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int cmax = min(a.C0 + a.C1, UW_CIC);
   float* xs = lds;
   float* dys = lds + cmax * UW_PS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = a.Wd / UW_TW;
-  const int x0 = (blockIdx.x % tiles_x) * UW_TW, y0 = (blockIdx.x / tiles_x) * UW_TH;
+  const int tiles_x = a.Wd / TW;
+  const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * UW_TH_;
   const long img0 = (long)blockIdx.y * a.img_per_wg;
   const long img1 = min(img0 + a.img_per_wg, a.n_img);
   const int Ci = a.C0 + a.C1;
@@ -357,9 +362,9 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
     const long grp = img / a.gsize;
     __syncthreads();                                                   // previous tile fully consumed
     // activated halo tile: interior quads as aligned float4, the two halo columns as scalars
-    for (int idx = tid; idx < cic * (UW_TH + 2) * (UW_TW / 4); idx += 256) {
-      const int c = idx / ((UW_TH + 2) * (UW_TW / 4)), r = idx - c * ((UW_TH + 2) * (UW_TW / 4));
-      const int yy = r / (UW_TW / 4), q = r - yy * (UW_TW / 4);
+    for (int idx = tid; idx < cic * (UW_TH_ + 2) * QPR; idx += 256) {
+      const int c = idx / ((UW_TH_ + 2) * QPR), r = idx - c * ((UW_TH_ + 2) * QPR);
+      const int yy = r / QPR, q = r - yy * QPR;
       const int y = y0 + yy - 1, x = x0 + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((unsigned)y < (unsigned)a.H) {
@@ -380,24 +385,25 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
       }
       *reinterpret_cast<float4*>(&xs[c * UW_PS + yy * UW_LDT + 4 + 4 * q]) = v;
     }
-    for (int idx = tid; idx < cic * (UW_TH + 2) * 2; idx += 256) {
-      const int c = idx / ((UW_TH + 2) * 2), r = idx - c * ((UW_TH + 2) * 2);
+    for (int idx = tid; idx < cic * (UW_TH_ + 2) * 2; idx += 256) {
+      const int c = idx / ((UW_TH_ + 2) * 2), r = idx - c * ((UW_TH_ + 2) * 2);
       const int yy = r >> 1, side = r & 1;
-      xs[c * UW_PS + yy * UW_LDT + (side ? UW_TW + 4 : 3)] =
-          ud_act(ca, img, grp, ci0 + c, y0 + yy - 1, side ? x0 + UW_TW : x0 - 1);
+      xs[c * UW_PS + yy * UW_LDT + (side ? TW + 4 : 3)] =
+          ud_act(ca, img, grp, ci0 + c, y0 + yy - 1, side ? x0 + TW : x0 - 1);
     }
-    for (int idx = tid; idx < a.Co * UW_TH * (UW_TW / 4); idx += 256) {
-      const int co = idx / (UW_TH * (UW_TW / 4)), r = idx - co * (UW_TH * (UW_TW / 4));
-      const int yy = r / (UW_TW / 4), q = r - yy * (UW_TW / 4);
+    for (int idx = tid; idx < a.Co * UW_TH_ * QPR; idx += 256) {
+      const int co = idx / (UW_TH_ * QPR), r = idx - co * (UW_TH_ * QPR);
+      const int yy = r / QPR, q = r - yy * QPR;
       const float4 d = ua_ld4(a.dy, img * a.dys + ((long)co * a.H + y0 + yy) * a.Wd + x0 + 4 * q, a.bfd);
-      *reinterpret_cast<float4*>(&dys[co * UW_DPS + yy * UW_TW + 4 * q]) = d;
+      *reinterpret_cast<float4*>(&dys[co * UW_DPS + yy * TW + 4 * q]) = d;
     }
     __syncthreads();
-    // this wave's two rows, 16 pixel quads each
+    // this wave's 32 pixel quads (two rows of the 8 x 64 tile, 4 / 8 rows of the narrower ones)
 #pragma unroll 2
     for (int it = 0; it < 32; ++it) {
-      const int yy = wave * 2 + (it >> 4), q = it & 15;
-      const int aoff = yy * UW_LDT + 4 * q, boff = yy * UW_TW + 4 * q;
+      const int pq = wave * 32 + it;
+      const int yy = pq / QPR, q = pq % QPR;
+      const int aoff = yy * UW_LDT + 4 * q, boff = yy * TW + 4 * q;
       float bv[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) bv[nb] = dys[bbase[nb] + boff] * bmask[nb];

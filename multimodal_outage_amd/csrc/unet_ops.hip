@@ -239,6 +239,28 @@ extern "C" int mo_conv3x3_flip_weights(const float* W, int Co, int Ci, float* Wf
   return mo_launch_status();
 }
 
+template <int NB, int MB, int TW>
+static void uw_launch1(const UdWgradArgs& a, int Ci, int Co, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;            // > 64 KB of dynamic LDS needs the attribute once per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)uw_wgrad_mfma_kernel<NB, MB, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((uw_wgrad_mfma_kernel<NB, MB, TW>), grid, dim3(256), uw_lds_bytes<TW>(Ci, Co, NB, MB), st, a);
+}
+template <int TW>
+static void uw_launch(const UdWgradArgs& a, int Ci, int Co, dim3 grid, hipStream_t st) {
+  const int cmax = Ci < UW_CIC ? Ci : UW_CIC;
+  if (Co <= 16) {
+    if (cmax * 9 <= 48) uw_launch1<1, 3, TW>(a, Ci, Co, grid, st);
+    else if (cmax * 9 <= 80) uw_launch1<1, 5, TW>(a, Ci, Co, grid, st);
+    else uw_launch1<1, 9, TW>(a, Ci, Co, grid, st);
+  } else {
+    if (cmax * 9 <= 48) uw_launch1<2, 3, TW>(a, Ci, Co, grid, st);
+    else if (cmax * 9 <= 80) uw_launch1<2, 5, TW>(a, Ci, Co, grid, st);
+    else uw_launch1<2, 9, TW>(a, Ci, Co, grid, st);
+  }
+}
 extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, const float* in0, int C0, long istride0,
                                      const float* sc0, const float* sh0, int relu0, const float* in1, int C1,
                                      long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
@@ -248,10 +270,12 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
   MO_CHECK_ARG(P < (1L << 31));
   const int Ci = C0 + C1;
   const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
-  if (Co <= 32 && (Wd % UW_TW) == 0 && (H % UW_TH) == 0 && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0 &&
+  const int uwt = ((Wd % 64) == 0 && (H % 8) == 0) ? 64 : ((Wd % 32) == 0 && (H % 16) == 0) ? 32
+                  : ((Wd % 16) == 0 && (H % 32) == 0) ? 16 : 0;
+  if (Co <= 32 && uwt && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0 &&
       mo_cdiv(Ci, UW_CIC) < 65536 && !mo_opt_no_mfma_wgrad) {
     // 3x3 weight gradient on the fp32 matrix pipe (unet_direct.hpp): the sum over pixels is the MFMA's k
-    const long tiles = (long)(Wd / UW_TW) * (H / UW_TH);
+    const long tiles = (long)(Wd / uwt) * (H / (512 / uwt));
     const long max_rows = ((long)Co * Ci * 9 <= UW_THIN_ROW) ? UW_THIN_SLABS : UD_MAX_SLABS;
     long ipw = (n_img * tiles + max_rows - 1) / max_rows;                 // images per workgroup
     if (ipw < 1) ipw = 1;
@@ -266,14 +290,9 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       a.bfd = (dtypes & MO_BF_DY) != 0; a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0;
       dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)a.n_cichunk);
       hipStream_t st = ST(stream);
-      const int cmax = Ci < UW_CIC ? Ci : UW_CIC;
-#define UW_LAUNCH1(NB, MB) do { static bool attr_set = false; const size_t lb = uw_lds_bytes(Ci, Co, NB, MB); \
-        if (!attr_set) { hipFuncSetAttribute((const void*)uw_wgrad_mfma_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL((uw_wgrad_mfma_kernel<NB, MB>), grid, dim3(256), lb, st, a); } while (0)
-#define UW_LAUNCH(NB) do { if (cmax * 9 <= 48) UW_LAUNCH1(NB, 3); else if (cmax * 9 <= 80) UW_LAUNCH1(NB, 5); else UW_LAUNCH1(NB, 9); } while (0)
-      if (Co <= 16) UW_LAUNCH(1); else UW_LAUNCH(2);
-#undef UW_LAUNCH
-#undef UW_LAUNCH1
+      if (uwt == 64) uw_launch<64>(a, Ci, Co, grid, st);
+      else if (uwt == 32) uw_launch<32>(a, Ci, Co, grid, st);
+      else uw_launch<16>(a, Ci, Co, grid, st);
       const long n = (long)Co * Ci * 9;
       hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(n, 32)), dim3(1024), 0, st, ws, n, (int)(tiles * nchunk), dW, n);
       return mo_launch_status();

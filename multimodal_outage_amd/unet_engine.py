@@ -45,7 +45,7 @@ def bf_ok(mode, Co, H, W):
     """bf16 storage of an activation tensor of Co channels at H x W: only where every kernel that touches it is a direct /
     streaming one (include/mo_hip.h `dtypes`): the MFMA weight gradient needs W % 64 == 0 and H % 8 == 0, the direct
     conv <= 32 output channels."""
-    return bool(mode == 'bf16' and Co <= 32 and H % 8 == 0 and W % 64 == 0 and H >= 64)
+    return bool(mode == 'bf16' and Co <= 32 and H % 8 == 0 and W % 64 == 0 and H >= 64)      # (narrower levels stay fp32)
 
 
 def _is_bf(t):

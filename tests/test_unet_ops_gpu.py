@@ -30,7 +30,9 @@ def act_view(y, sc, sh, gsize):
                                                 # deep levels on the matrix pipe (ux_conv3x3_mfma_kernel): 1..4 blocks of 16 output channels,
                                                 # 8x32 and 16x16 tiles, two views, ragged channel chunks
                                                 (2, 1, 16, 0, 32, 32, 32), (2, 2, 32, 0, 64, 16, 16), (2, 1, 32, 32, 32, 32, 32),
-                                                (3, 1, 24, 8, 48, 16, 32), (2, 2, 8, 0, 20, 64, 64), (2, 1, 13, 0, 8, 16, 16)])
+                                                (3, 1, 24, 8, 48, 16, 32), (2, 2, 8, 0, 20, 64, 64), (2, 1, 13, 0, 8, 16, 16),
+                                                # MFMA weight gradient on 16x32 and 32x16 tiles
+                                                (3, 1, 16, 0, 32, 32, 32), (2, 2, 32, 32, 32, 48, 32), (2, 1, 8, 0, 16, 64, 16), (5, 1, 20, 0, 12, 32, 48)])
 @pytest.mark.parametrize('bf', [0, 1])
 def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
     """bf=1: the same layer with its activation tensors (in0, out, dy; in1 = the fp32 upsampled map of an Up block)
