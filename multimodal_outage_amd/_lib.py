@@ -67,6 +67,8 @@ SIGNATURES = {
     'mo_conv3x3_fwd': (i32, [vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32, vp, i32, i64, i32, i32,
                              vp, i64, vp, i32, vp]),
     'mo_conv3x3_stats_tiles': (i32, [i32, i64, i32, i32]),
+    'mo_conv3x3_stats_tiles2': (i32, [i32, i32, i64, i32, i32, i32]),
+    'mo_conv3x3_bf16_route': (i32, [i32, i32, i64, i32, i32]),
     'mo_conv3x3_flip_weights': (i32, [vp, i32, i32, vp, vp]),
     'mo_unet_wgrad_ws_floats': (i64, [i32, i32, i64]),
     'mo_conv3x3_bwd_weight': (i32, [vp, i64, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32,
@@ -123,6 +125,7 @@ def check(code, what=''):
 
 
 BF_IN0, BF_IN1, BF_OUT, BF_DY, BF_DP = 1, 2, 4, 8, 16     # `dtypes` flags of the UNet entry points (include/mo_hip.h)
+BF_MATH, W_FLIP = 32, 64                                  # bf16 matrix-pipe arithmetic; weights read transposed + flipped
 
 
 def ptr(t):

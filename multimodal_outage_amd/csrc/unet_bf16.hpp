@@ -1,0 +1,306 @@
+// 3x3 convolutions of the UNet on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, fp32 accumulation) -- the arithmetic of
+// the "bf16 mode" of BASELINE config 3 (MO_BF_MATH in `dtypes`): activations and weights enter the MFMA rounded to bf16
+// (round to nearest even), every sum is fp32.  The fp32 kernels of unet_direct.hpp spend their time on the VALU (thin
+// layers, 20..40 % of the 78 TFLOP/s scalar-FMA peak) or on a 4x-padded fp32 MFMA; on this pipe the arithmetic of a thin
+// conv is a few percent of its memory time, so the kernels below are organised around the staging of the tile.
+//
+// Forward / data gradient (ub_conv3x3_kernel):  D[pixel][co] += A[pixel][k] * B[k][co],  k = (tap, ci)
+//   * the activated input tile (folded BatchNorm affine + ReLU on the way in, zero padding AFTER activation) lies in LDS
+//     CHANNELS-LAST as bf16: [row][col][CP], so the 8 consecutive k a lane feeds to one MFMA are 16 contiguous bytes
+//     (CP >= 8: eight channels of one tap; CP == 4: four channels of two neighbouring taps of a row);
+//   * rows of D are 16 consecutive pixels of an image row, so a lane ends up with 4 consecutive pixels of one output
+//     channel (8 / 16 bytes of the NCHW result) and the BatchNorm statistics come straight from the accumulators;
+//   * the weights are gathered once per workgroup from the fp32 (Co, Ci, 3, 3) tensor into B fragments held in registers
+//     (the data gradient reads the same tensor transposed and flipped: no flipped copy is made); a workgroup walks a
+//     range of images at one tile position.
+#pragma once
+#include "unet_direct.hpp"
+
+typedef __bf16 ub_bf8 __attribute__((ext_vector_type(8)));
+typedef float ub_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned ub_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned ub_u4 __attribute__((ext_vector_type(4)));
+
+struct UbConvArgs {
+  UdConvArgs c;
+  int flip;                 // 1: W is the forward conv's (Ci, Co, 3, 3) tensor, use W[ci][co][8 - tap] (data gradient)
+  int n_img, img_per_wg;
+};
+
+typedef float ub_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ub_bf2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned ub_pack2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((ub_f2){lo, hi}, ub_bf2));
+}
+template <bool B> struct UbBool { static constexpr bool value = B; };
+
+#define UB_TW 64
+#define UB_TH 16
+#define UB_OOB 0x80000000u  // a byte offset no descriptor of this file covers (images are < 2 GiB): loads give 0, stores are dropped
+
+// One descriptor per (tensor, image): a lane's 32-bit byte offset inside the image is computed ONCE per kernel (the
+// staging pattern of a thread is the same for every image and band), rows outside the image / channels past the
+// source's count / unused lanes read as zero through the range check -- the stage has no branches and no 64-bit
+// address arithmetic.  (The first version computed 64-bit addresses and the BatchNorm affine per task and channel:
+// ~400 VALU instructions per 16 values, 45 us of a 119 us launch with the global loads removed.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ub_rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+
+template <int CP, int NB, int RB, bool TWO>   // padded input channels (4, 8, 16, 32), blocks of 16 output channels, rows per
+                                               // band, TWO: two views of CP/2 channels each (the skip / up concat)
+__global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
+  constexpr int TW = UB_TW, TH = UB_TH, LDT = TW + 8;     // col = x - x0 + 4: whole quads x0-4 .. x0+TW+3 are staged
+  constexpr int CPC = CP >= 8 ? CP / 8 : 1;               // 16-byte chunks per pixel
+  constexpr int NCH = CP == 4 ? 6 : 9 * CPC;              // k chunks of 8
+  constexpr int NM = (NCH + 3) / 4;                       // MFMAs per 16-pixel block and output block
+  constexpr int NR = RB + 2, QH = TW / 4 + 2;
+  constexpr int CQS = TWO ? CP / 8 : CP / 4;              // channel quads per source
+  constexpr int NTASK = CQS * NR * QH;                    // staging tasks per source and band (4 pixels x 4 channels each)
+  constexpr int NTS = (NTASK + 255) / 256;                // ... per thread
+  constexpr int NT = TWO ? 2 * NTS : NTS;                 // task t < NTS reads the first view, the others the second
+  constexpr int WR = RB / 4;                              // rows of a band per wave
+  __shared__ __attribute__((aligned(16))) unsigned short tile[NR * LDT * CP];
+  __shared__ __attribute__((aligned(16))) float aff[2][CP];   // folded BatchNorm affine of the current image group
+  __shared__ float red[4][32 * NB];
+  const UdConvArgs& a = A.c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
+  const int tiles_x = a.Wd / TW;
+  const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
+  const int Ci = a.C0 + a.C1;
+  const int es0 = a.bf0 ? 2 : 4, es1 = a.bf1 ? 2 : 4, eso = a.bfo ? 2 : 4;
+  const int HW = a.H * a.Wd;
+
+  // B fragments: lane (co = lp, chunk = 4m + lg) holds 8 consecutive k
+  ub_bf8 wf[NM][NB];
+  {
+    float wr[NM][NB][8];                                  // branch-free gather: every load is in flight before the first use
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int co = nb * 16 + lp, c = 4 * m + lg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int ci, tap;
+          bool ok = c < NCH && co < a.Co;
+          if (CP == 4) { const int kx = 2 * (c & 1) + (j >> 2); ci = j & 3; tap = (c >> 1) * 3 + kx; ok = ok && kx < 3; }
+          else { tap = c / CPC; ci = (c % CPC) * 8 + j; }
+          ok = ok && ci < Ci;
+          const int cic = min(ci, Ci - 1), coc = min(co, a.Co - 1), tc = min(tap, 8);
+          const float w = a.W[A.flip ? ((long)cic * a.Co + coc) * 9 + 8 - tc : ((long)coc * Ci + cic) * 9 + tc];
+          wr[m][nb][j] = ok ? w : 0.f;
+        }
+      }
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[m][nb][j] = (__bf16)wr[m][nb][j];
+  }
+  // A fragments: LDS byte address of this lane's chunk in the first 16-pixel block of its first row
+  int abase[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    int c = 4 * m + lg;
+    if (c >= NCH) c = 0;                                  // (its weights are zero; any finite data will do)
+    int o;
+    if (CP == 4) o = (((c >> 1) * LDT + lp + 2 * (c & 1) + 3) * CP) * 2;
+    else { const int tap = c / CPC, ky = tap / 3, kx = tap - 3 * ky; o = ((ky * LDT + lp + kx + 3) * CP + (c % CPC) * 8) * 2; }
+    abase[m] = o + wave * WR * LDT * CP * 2;
+  }
+  // staging tasks of this thread: the same for every image and band.  toff: byte offset inside the image of
+  // (first channel of the quad, row y0 + r - 1, column x); trow: that row, or far outside for lanes without a task /
+  // columns outside the image; tdst: LDS element of (row r, column, channel quad)
+  int toff[NTS], trow[NTS], tdst[NTS];
+#pragma unroll
+  for (int t = 0; t < NTS; ++t) {
+    const int idx = tid + t * 256;
+    const int cq = idx / (NR * QH), r2 = idx - cq * (NR * QH), r = r2 / QH, q = r2 - r * QH;
+    const int x = x0 + 4 * q - 4;
+    toff[t] = (cq * 4 * a.H + y0 + r - 1) * a.Wd + x;     // in ELEMENTS (the two views may differ in width)
+    trow[t] = (idx < NTASK && (unsigned)x < (unsigned)a.Wd) ? y0 + r - 1 : -(1 << 24);
+    tdst[t] = (idx < NTASK) ? (r * LDT + 4 * q) * CP + cq * 4 : -1;
+  }
+  // output: lane (co = lp + 16 nb, pixels 4 lg .. 4 lg + 3 of a block)
+  unsigned vout[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    vout[nb] = (nb * 16 + lp < a.Co) ? (unsigned)((((nb * 16 + lp) * a.H + y0 + wave * WR) * a.Wd + x0 + 4 * lg) * eso) : UB_OOB;
+
+  // ---- the workgroup's stages: (image, band of RB rows) in order.  Software pipeline: the global loads of stage k+1 are
+  // issued in front of the matrix phase of stage k and wait in registers, so their latency is covered by it:
+  //   barrier | convert + write LDS (stage k) | barrier | issue loads (k+1) | matrix phase (k) | ...
+  constexpr int NBI = TH / RB;                            // bands per image
+  const long img0 = (long)blockIdx.y * A.img_per_wg;
+  const long img1 = min(img0 + (long)A.img_per_wg, (long)A.n_img);
+  const int nstage = (int)(img1 - img0) * NBI;
+  ub_u4 raw[NT][4];
+
+  auto load_view = [&](auto bfc, const int sec, const long img, const int b) {
+    constexpr bool BF = decltype(bfc)::value;
+    constexpr int es = BF ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t rs = sec ? ub_rsrc(reinterpret_cast<const char*>(a.in1) + img * a.is1 * es, (long)a.C1 * HW * es)
+                                          : ub_rsrc(reinterpret_cast<const char*>(a.in0) + img * a.is0 * es, (long)a.C0 * HW * es);
+    const int pb = HW * es;                               // channels past the view's count fall out of the descriptor's range
+#pragma unroll
+    for (int tl = 0; tl < NTS; ++tl) {
+      const unsigned off = (unsigned)((toff[tl] + b * RB * a.Wd) * es);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ub_u4& d = raw[sec * NTS + tl][j];
+        if (BF) { const ub_u2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(off + j * pb), 0, 0); d[0] = u[0]; d[1] = u[1]; }
+        else d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + j * pb), 0, 0);
+      }
+    }
+  };
+  auto issue_loads = [&](const int k) {
+    const long img = img0 + k / NBI;
+    const int b = k % NBI;
+    if (a.bf0) load_view(UbBool<true>{}, 0, img, b); else load_view(UbBool<false>{}, 0, img, b);
+    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, 1, img, b); else load_view(UbBool<false>{}, 1, img, b); }
+  };
+  // activation (folded BatchNorm affine, ReLU), rounding to bf16, transposition to channels-last, LDS
+  auto commit_view = [&](auto bfc, const int sec, const int b) {
+    constexpr bool BF = decltype(bfc)::value;
+    const float flo = (sec ? a.relu1 : a.relu0) ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int tl = 0; tl < NTS; ++tl) {
+      const int dsta = tdst[tl] + (sec ? CP / 2 : 0);     // (channel position inside the pixel)
+      const int ch = (dsta < 0 ? 0 : dsta) & (CP - 1);
+      const float4 sc4 = *reinterpret_cast<const float4*>(&aff[0][ch]);
+      const float4 sh4 = *reinterpret_cast<const float4*>(&aff[1][ch]);
+      const float scj[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shj[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+      // zero padding comes AFTER the activation: rows / columns outside the image are zero, not relu(shift); what the
+      // loads brought from there (a neighbouring row or plane, or the range check's zero) is multiplied away
+      const float keep = ((unsigned)(trow[tl] + b * RB) < (unsigned)a.H) ? 1.f : 0.f;
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const ub_u4& d = raw[sec * NTS + tl][j];
+        const unsigned ux = d[0], uy = d[1];
+        if (BF) v[j] = make_float4(ua_lo(ux), ua_hi(ux), ua_lo(uy), ua_hi(uy));
+        else { const unsigned uz = d[2], uw = d[3];
+               v[j] = make_float4(__uint_as_float(ux), __uint_as_float(uy), __uint_as_float(uz), __uint_as_float(uw)); }
+        const float s_ = scj[j] * keep, t_ = shj[j] * keep;
+        v[j].x = fmaxf(v[j].x * s_ + t_, flo); v[j].y = fmaxf(v[j].y * s_ + t_, flo);
+        v[j].z = fmaxf(v[j].z * s_ + t_, flo); v[j].w = fmaxf(v[j].w * s_ + t_, flo);
+      }
+      const uint2 p0 = make_uint2(ub_pack2(v[0].x, v[1].x), ub_pack2(v[2].x, v[3].x));
+      const uint2 p1 = make_uint2(ub_pack2(v[0].y, v[1].y), ub_pack2(v[2].y, v[3].y));
+      const uint2 p2 = make_uint2(ub_pack2(v[0].z, v[1].z), ub_pack2(v[2].z, v[3].z));
+      const uint2 p3 = make_uint2(ub_pack2(v[0].w, v[1].w), ub_pack2(v[2].w, v[3].w));
+      if (tdst[tl] >= 0) {
+        unsigned short* dst = &tile[dsta];
+        if (CP == 4) {
+          *reinterpret_cast<uint4*>(dst) = make_uint4(p0.x, p0.y, p1.x, p1.y);
+          *reinterpret_cast<uint4*>(dst + 8) = make_uint4(p2.x, p2.y, p3.x, p3.y);
+        } else {
+          *reinterpret_cast<uint2*>(dst) = p0; *reinterpret_cast<uint2*>(dst + CP) = p1;
+          *reinterpret_cast<uint2*>(dst + 2 * CP) = p2; *reinterpret_cast<uint2*>(dst + 3 * CP) = p3;
+        }
+      }
+    }
+  };
+  float s1[NB], s2[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+  auto matrix_phase = [&](auto bfoc, const long img, const int b) {
+    constexpr bool BFO = decltype(bfoc)::value;
+    constexpr int eo = BFO ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t ro = ub_rsrc(reinterpret_cast<char*>(a.out) + img * a.os * eo, (long)a.Co * HW * eo);
+    const char* lds = reinterpret_cast<const char*>(tile);
+#pragma unroll 1
+    for (int rr = 0; rr < WR; ++rr) {
+      unsigned vo[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) vo[nb] = vout[nb] + (unsigned)((b * RB + rr) * a.Wd * eo);   // (UB_OOB stays out of range)
+#pragma unroll
+      for (int cb = 0; cb < TW / 16; ++cb) {
+        ub_f4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const char* ap = lds + (abase[m] + rr * (LDT * CP * 2)) + cb * 16 * CP * 2;
+          ub_bf8 af;
+          if (CP == 4) {                                  // 8-byte aligned only
+            const uint2 lo = *reinterpret_cast<const uint2*>(ap);
+            const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
+            af = __builtin_bit_cast(ub_bf8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          } else {
+            af = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const uint4*>(ap));
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[m][nb], acc[nb], 0, 0, 0);
+        }
+        // D[pixel 4*lg + r][co = lp]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float c0 = acc[nb][0], c1 = acc[nb][1], c2 = acc[nb][2], c3 = acc[nb][3];
+          if (BFO) {
+            const ub_u2 pk = {ub_pack2(c0, c1), ub_pack2(c2, c3)};
+            __builtin_amdgcn_raw_buffer_store_b64(pk, ro, (int)(vo[nb] + cb * 32), 0, 0);
+          } else {
+            const ub_u4 pk = {__float_as_uint(c0), __float_as_uint(c1), __float_as_uint(c2), __float_as_uint(c3)};
+            __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)(vo[nb] + cb * 64), 0, 0);
+          }
+          s1[nb] += (c0 + c1) + (c2 + c3);
+          s2[nb] += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
+        }
+      }
+    }
+  };
+  auto load_affine = [&](const long img) {                // folded BatchNorm affine of the image's group -> LDS
+    if (tid < CP) {
+      const long grp = img / a.gsize;
+      float s_ = 0.f, t_ = 0.f;
+      const bool sec = TWO && tid >= CP / 2;
+      const int cc = sec ? tid - CP / 2 : tid;
+      if (cc < (sec ? a.C1 : a.C0)) {
+        const float* sc = sec ? a.sc1 : a.sc0;
+        const float* sh = sec ? a.sh1 : a.sh0;
+        const long gi = grp * (sec ? a.C1 : a.C0) + cc;
+        s_ = sc ? sc[gi] : 1.f; t_ = sc ? sh[gi] : 0.f;
+      }
+      aff[0][tid] = s_; aff[1][tid] = t_;
+    }
+  };
+
+  if (nstage > 0) { load_affine(img0); issue_loads(0); }
+#pragma unroll 1
+  for (int k = 0; k < nstage; ++k) {
+    const long img = img0 + k / NBI;
+    const int b = k % NBI;
+    __syncthreads();                                      // stage k-1's matrix phase is done with the tile; aff is in place
+    if (a.bf0) commit_view(UbBool<true>{}, 0, b); else commit_view(UbBool<false>{}, 0, b);
+    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, 1, b); else commit_view(UbBool<false>{}, 1, b); }
+    __syncthreads();
+    if (k + 1 < nstage) {
+      issue_loads(k + 1);
+      if (b == NBI - 1 && (img + 1) % a.gsize == 0) load_affine(img + 1);     // (every reader of aff is past the barrier)
+    }
+    if (a.bfo) matrix_phase(UbBool<true>{}, img, b); else matrix_phase(UbBool<false>{}, img, b);
+    if (b == NBI - 1) {
+      if (a.stats) {                                      // per-tile BatchNorm statistics from the accumulators
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          float t1 = s1[nb], t2 = s2[nb];
+          t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+          t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+          if (lg == 0) { red[wave][2 * (nb * 16 + lp)] = t1; red[wave][2 * (nb * 16 + lp) + 1] = t2; }
+        }
+        __syncthreads();
+        if (tid < 32 * NB && (tid >> 1) < a.Co) {
+          const long ntile = gridDim.x;
+          a.stats[((img * ntile + blockIdx.x) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
+              (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+    }
+  }
+}

@@ -10,6 +10,7 @@
 #include "mo_gemm.hpp"
 #include "unet_direct.hpp"
 #include "unet_thin.hpp"
+#include "unet_bf16.hpp"
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
@@ -19,13 +20,17 @@
 #define MO_BF_OUT 4
 #define MO_BF_DY 8
 #define MO_BF_DP 16
+#define MO_BF_MATH 32
+#define MO_W_FLIP 64
 static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 = previous VALU / split-K weight gradients
 static int mo_opt_no_mfma_conv = 0;      // 1 = deep-level convs on the im2col tile engine / VALU direct kernel as before
+static int mo_opt_no_bf16_mfma = 0;      // 1 = MO_BF_MATH requests run on the fp32 kernels (A/B switch)
 static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
 extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!name) return MO_EINVAL;
   if (!strcmp(name, "no_mfma_wgrad")) { mo_opt_no_mfma_wgrad = value; return MO_OK; }
   if (!strcmp(name, "no_mfma_conv")) { mo_opt_no_mfma_conv = value; return MO_OK; }
+  if (!strcmp(name, "no_bf16_mfma")) { mo_opt_no_bf16_mfma = value; return MO_OK; }
   if (!strcmp(name, "ux_min_co")) { mo_opt_ux_min_co = value; return MO_OK; }
   return MO_EINVAL;
 }
@@ -165,6 +170,28 @@ static int ux_tw(int Co, long n_img, int H, int Wd) {
   return 0;
 }
 static bool ux_preferred(int Co, int H, int Wd) { return Co >= mo_opt_ux_min_co || H < 32 || Wd < 32; }
+// bf16 matrix-pipe conv (unet_bf16.hpp): images that tile exactly into 16 x 64 pixels, <= 32 channels either side
+extern "C" int mo_conv3x3_bf16_route(int Ci, int Co, long n_img, int H, int Wd) {
+  return !mo_opt_no_bf16_mfma && Ci > 0 && Co > 0 && Ci <= 32 && Co <= 32 && (Wd % UB_TW) == 0 && (H % UB_TH) == 0 &&
+         n_img > 0 && n_img < (1L << 31) && (long)(Ci > Co ? Ci : Co) * H * Wd * 4 < (1L << 31);
+}
+extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
+extern "C" int mo_conv3x3_stats_tiles2(int Ci, int Co, long n_img, int H, int Wd, int dtypes) {
+  if ((dtypes & MO_BF_MATH) && mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) return (Wd / UB_TW) * (H / UB_TH);
+  return mo_conv3x3_stats_tiles(Co, n_img, H, Wd);
+}
+template <int CP, int RB>
+static void ub_launch(const UbConvArgs& A, int Co, bool two, dim3 grid, hipStream_t st) {
+  if constexpr (CP >= 8) {
+    if (two) {
+      if (Co <= 16) hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 1, RB, true>), grid, dim3(256), 0, st, A);
+      else hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 2, RB, true>), grid, dim3(256), 0, st, A);
+      return;
+    }
+  }
+  if (Co <= 16) hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 1, RB, false>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 2, RB, false>), grid, dim3(256), 0, st, A);
+}
 extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd) {
   const int tw = ux_tw(Co, n_img, H, Wd);
   if (tw && ux_preferred(Co, H, Wd)) return (Wd / tw) * (H / (256 / tw));
@@ -184,6 +211,32 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
   // thin layers at >= 32x32 pixels: direct convolution on LDS spatial tiles (unet_direct.hpp)
   const bool al16 = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0)) &&
                     (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0;
+  // (two views: the skip / up concat of equal halves, 4 + 4 .. 16 + 16 channels)
+  if ((dtypes & MO_BF_MATH) && al16 && (C1 == 0 || (C0 == C1 && (C0 == 4 || C0 == 8 || C0 == 16))) &&
+      mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) {
+    UbConvArgs A;
+    UdConvArgs& a = A.c;
+    a.stats = stats;
+    a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0; a.bfo = (dtypes & MO_BF_OUT) != 0;
+    a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
+    a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
+    a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+    A.flip = (dtypes & MO_W_FLIP) != 0; A.n_img = (int)n_img;
+    const long tiles = (long)(Wd / UB_TW) * (H / UB_TH);
+    long ipw = (tiles * n_img) / 1024;                    // images per workgroup (weights / staging pattern are set up once per workgroup)
+    if (ipw < 1) ipw = 1;
+    while ((n_img + ipw - 1) / ipw >= 65536) ++ipw;
+    A.img_per_wg = (int)ipw;
+    dim3 grid((unsigned)tiles, (unsigned)((n_img + ipw - 1) / ipw));
+    hipStream_t st = ST(stream);
+    if (Ci <= 4) ub_launch<4, 16>(A, Co, false, grid, st);
+    else if (Ci <= 8) ub_launch<8, 16>(A, Co, C1 > 0, grid, st);
+    else if (Ci <= 16) ub_launch<16, 8>(A, Co, C1 > 0, grid, st);
+    else ub_launch<32, 4>(A, Co, C1 > 0, grid, st);
+    return mo_launch_status();
+  }
+  if (dtypes & MO_W_FLIP) return MO_EUNSUPPORTED;     // only the bf16 matrix-pipe kernel reads the weights transposed
+  dtypes &= ~MO_BF_MATH;                              // the fp32 kernels serve the request with fp32 arithmetic
   const int uxw = al16 ? ux_tw(Co, n_img, H, Wd) : 0;
   if (uxw && ux_preferred(Co, H, Wd)) {
     UdConvArgs a;
@@ -266,6 +319,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
                                      long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
                                      long n_img, int H, int Wd, float* dW, float* ws, int dtypes, void* stream) {
   MO_CHECK_ARG(dy && in0 && dW && ws && C0 > 0 && C1 >= 0 && Co > 0 && n_img > 0 && (Wd % 4) == 0);
+  dtypes &= ~MO_BF_MATH;                              // (no bf16 matrix-pipe weight gradient yet: fp32 arithmetic)
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31));
   const int Ci = C0 + C1;

@@ -71,16 +71,17 @@ class Grads(dict):
         return tuple(None if (k in self.gout and self.gout[k] is not None) else self.get(k) for k in names)
 
 
-def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev, out_bf=False):
+def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev, out_bf=False, math=False):
     v0 = views[0]
     H, W = v0.H, v0.W
     st = L.stream()
     y = _empty(n, Co, H, W, dev=dev, bf=out_bf)
     a1 = views[1].args() if len(views) > 1 else _NOVIEW
-    dt = (L.BF_IN0 * v0.bf) | (L.BF_IN1 * (views[1].bf if len(views) > 1 else 0)) | (L.BF_OUT * int(out_bf))
+    dt = (L.BF_IN0 * v0.bf) | (L.BF_IN1 * (views[1].bf if len(views) > 1 else 0)) | (L.BF_OUT * int(out_bf)) | \
+         (L.BF_MATH * int(math))
     # train mode: the BatchNorm statistics come out of the conv's own epilogue where the direct kernels run
     # (per-tile partial sums), else from one pass over the output
-    ntile = L.load().mo_conv3x3_stats_tiles(Co, n, H, W) if training else 0
+    ntile = L.load().mo_conv3x3_stats_tiles2(sum(v.C for v in views), Co, n, H, W, dt) if training else 0
     stats = _empty(n, ntile, Co, 2, dev=dev) if ntile else None
     L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, L.ptr(stats), dt, st)
     G = n // gs
@@ -97,16 +98,17 @@ def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev, out_bf=False
     return y, aff
 
 
-def double_conv_fwd(p, pre, views, Co, n, gs, training, bufs, dev, bf=(False, False)):
-    """unet.py:40-53.  Returns (saved, output view).  bf = (y1, y2 stored as bf16)."""
+def double_conv_fwd(p, pre, views, Co, n, gs, training, bufs, dev, bf=(False, False), math=False):
+    """unet.py:40-53.  Returns (saved, output view).  bf = (y1, y2 stored as bf16); math: the convs (and their gradients)
+    on the bf16 matrix pipe where a kernel exists (MO_BF_MATH; fp32 accumulation)."""
     H, W = views[0].H, views[0].W
     y1, aff1 = _conv_bn(p, pre + '.double_conv.0.weight', pre + '.double_conv.1', views, Co, n, gs, training, bufs, dev,
-                        bf[0])
+                        bf[0], math)
     v1 = View(y1, Co, H, W, aff1[0], aff1[1])
     y2, aff2 = _conv_bn(p, pre + '.double_conv.3.weight', pre + '.double_conv.4', [v1], Co, n, gs, training, bufs, dev,
-                        bf[1])
+                        bf[1], math)
     v2 = View(y2, Co, H, W, aff2[0], aff2[1])
-    return dict(pre=pre, views=views, y1=y1, aff1=aff1, v1=v1, y2=y2, aff2=aff2, Co=Co, H=H, W=W), v2
+    return dict(pre=pre, views=views, y1=y1, aff1=aff1, v1=v1, y2=y2, aff2=aff2, Co=Co, H=H, W=W, math=math), v2
 
 
 def _flip(W, dev):
@@ -133,6 +135,7 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
     st = L.stream()
     pre, Co, H, W = sv['pre'], sv['Co'], sv['H'], sv['W']
     HW = H * W
+    math = L.BF_MATH * int(sv.get('math', False))
 
     def act_bwd(y, aff, bnkey, da_t, dp_t):
         dy = _empty(n, Co, H, W, dev=dev, bf=_is_bf(y))          # the gradient of a conv output is stored as the output is
@@ -151,16 +154,22 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
         dW = grads.buf(wkey, (Co, Ci, 3, 3))
         ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * HW), device=dev, dtype=torch.float32)
         a1 = views[1].args() if len(views) > 1 else _NOVIEW
-        dt = (L.BF_DY * _is_bf(dy)) | (L.BF_IN0 * views[0].bf) | (L.BF_IN1 * (views[1].bf if len(views) > 1 else 0))
+        dt = (L.BF_DY * _is_bf(dy)) | (L.BF_IN0 * views[0].bf) | (L.BF_IN1 * (views[1].bf if len(views) > 1 else 0)) | math
         L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * HW, Co, *views[0].args(), *a1, gs, n, H, W, L.ptr(dW),
                L.ptr(ws), dt, st)
 
     def dgrad(dy, Wt, out_bf):
         Ci = Wt.shape[1]
-        Wf = _flip(Wt, dev)
         dx = _empty(n, Ci, H, W, dev=dev, bf=out_bf)
+        dt = (L.BF_IN0 * _is_bf(dy)) | (L.BF_OUT * int(out_bf))
+        if math and lib.mo_conv3x3_bf16_route(Co, Ci, n, H, W):
+            # the bf16 matrix-pipe kernel reads the forward weights transposed + flipped in place
+            L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wt), Ci, n, H, W,
+                   L.ptr(dx), Ci * HW, None, dt | math | L.W_FLIP, st)
+            return dx
+        Wf = _flip(Wt, dev)
         L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wf), Ci, n, H, W,
-               L.ptr(dx), Ci * HW, None, (L.BF_IN0 * _is_bf(dy)) | (L.BF_OUT * int(out_bf)), st)
+               L.ptr(dx), Ci * HW, None, dt, st)
         return dx
 
     dy2 = act_bwd(sv['y2'], sv['aff2'], pre + '.double_conv.4', da, dp)
@@ -259,7 +268,9 @@ class UnetEncodeFn(torch.autograd.Function):
         saved = []
         mode = state.get('act_dtype', 'f32')      # 'bf16': conv outputs / gradients of the large levels stored as bf16
         b0 = bf_ok(mode, 4, S, S)
-        sv, v = double_conv_fwd(p, 'contraction.inc', [View(x, Cin, S, S)], 4, n, gs, training, bufs, dev, bf=(b0, b0))
+        math = mode == 'bf16'
+        sv, v = double_conv_fwd(p, 'contraction.inc', [View(x, Cin, S, S)], 4, n, gs, training, bufs, dev, bf=(b0, b0),
+                                math=math)
         saved.append(sv)
         views = [v]
         for k, (ci, co) in enumerate(ENC_CH, 1):
@@ -269,7 +280,7 @@ class UnetEncodeFn(torch.autograd.Function):
             L.call('mo_unet_act', L.ptr(v.t), v.istride, ci, n, H, H, L.ptr(v.sc), L.ptr(v.sh), gs, 1, L.ptr(pooled),
                    ci * (H // 2) * (H // 2), (L.BF_IN0 * v.bf) | (L.BF_OUT * int(bk)), st)
             sv, v = double_conv_fwd(p, f'contraction.down{k}.maxpool_conv.1', [View(pooled, ci, H // 2, H // 2)], co, n,
-                                    gs, training, bufs, dev, bf=(bk, bk))
+                                    gs, training, bufs, dev, bf=(bk, bk), math=math)
             saved.append(sv)
             views.append(v)
         v5 = views[-1]
@@ -342,7 +353,8 @@ class UnetDecodeFn(torch.autograd.Function):
             # feeds the next ConvTranspose2d, which runs on the fp32 tile engine, and stays fp32 (as does u)
             bk = bf_ok(state.get('act_dtype', 'f32'), co, 2 * H, 2 * H)
             sv, vn = double_conv_fwd(p, f'expansion.up{k}.conv', [sk, View(u, ci // 2, 2 * H, 2 * H)], co, n, gs,
-                                     training, bufs, dev, bf=(bk, bk and k == 4))
+                                     training, bufs, dev, bf=(bk, bk and k == 4),
+                                     math=state.get('act_dtype', 'f32') == 'bf16')
             ups.append(dict(vin=v, dc=sv, ci=ci, H=H))
             v = vn
         Wo, bo = p['expansion.outc.conv.weight'], p['expansion.outc.conv.bias']

@@ -89,6 +89,60 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
     close(dW, Wt.grad, what='conv dW')
 
 
+@pytest.mark.parametrize('n,gs,C0,C1,Co,H,W', [(4, 2, 4, 0, 4, 16, 64), (3, 1, 13, 0, 4, 32, 64), (2, 2, 4, 4, 4, 16, 128),
+                                                (2, 1, 8, 0, 8, 32, 128), (2, 2, 8, 8, 8, 16, 64), (2, 1, 8, 0, 16, 64, 64),
+                                                (2, 1, 16, 16, 16, 16, 64), (3, 3, 16, 0, 32, 16, 64), (2, 1, 16, 16, 32, 32, 64), (2, 1, 20, 0, 32, 32, 64),
+                                                (2, 2, 5, 0, 13, 16, 64), (70, 2, 4, 0, 8, 64, 128), (40, 2, 8, 8, 20, 16, 64)])
+@pytest.mark.parametrize('bf', [0, 1])
+def test_conv3x3_bf16_matrix_pipe(L, n, gs, C0, C1, Co, H, W, bf):
+    """MO_BF_MATH: the 3x3 conv, its data gradient (weights read transposed + flipped, MO_W_FLIP) and its weight gradient
+    on the bf16 matrix pipe (unet_bf16.hpp).  Operands enter the MFMA rounded to bf16 and every sum is fp32, so the
+    yardstick is the fp32 CPU conv of the SAME bf16-rounded operands (1e-3 of scale: accumulation order, plus the few
+    activations whose fused-multiply-add affine lands on the other side of a bf16 rounding boundary); the unrounded conv
+    is checked at the bf16 tolerance.  bf=1: activations stored as bf16 as well."""
+    lib = L.load()
+    assert lib.mo_conv3x3_bf16_route(C0 + C1, Co, n, H, W) == 1 and (C1 == 0 or C0 == C1)
+    G = n // gs
+    rb = lambda t: t.to(torch.bfloat16).float()
+    q = rb if bf else (lambda t: t)
+    x0 = q(rand(1, (n, C0, H, W)))
+    sc0, sh0 = rand(2, (G, C0)) * 0.3 + 1, rand(3, (G, C0)) * 0.3
+    ins = [act_view(x0, sc0, sh0, gs)]
+    if C1:
+        x1 = rand(4, (n, C1, H, W))
+        ins.append(x1)
+    Ci = C0 + C1
+    Wt = rand(5, (Co, Ci, 3, 3)) / np.sqrt(9 * Ci)
+    cat = torch.cat(ins, 1)
+    ref_q = F.conv2d(rb(cat), rb(Wt), None, padding=1)
+    ref = F.conv2d(cat, Wt, None, padding=1)
+    out = torch.empty(n, Co, H, W, device='cuda', dtype=torch.bfloat16 if bf else torch.float32)
+    x0d = dev(x0.to(torch.bfloat16) if bf else x0)
+    x1d = dev(x1) if C1 else None
+    args_in = (L.ptr(x0d), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1, L.ptr(x1d), C1, C1 * H * W, None, None, 0)
+    dt = L.BF_MATH | ((L.BF_IN0 | L.BF_OUT) if bf else 0)
+    ntile = lib.mo_conv3x3_stats_tiles2(Ci, Co, n, H, W, dt)
+    assert ntile == (W // 64) * (H // 16)
+    stats = torch.full((n, ntile, Co, 2), float('nan'), device='cuda')
+    Wd_ = dev(Wt)
+    L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(Wd_), Co, n, H, W, L.ptr(out), Co * H * W, L.ptr(stats), dt, L.stream())
+    close(out.float(), ref_q, tol=4e-3 if bf else 1e-3, what='conv fwd vs bf16-rounded operands')
+    close(out.float(), ref, tol=1.5e-2, what='conv fwd vs fp32 conv')
+    st = stats.cpu().double().sum(1)
+    rd = ref_q.double()
+    close(st[..., 0], rd.sum((2, 3)), tol=1e-3, what='epilogue sum')
+    close(st[..., 1], (rd * rd).sum((2, 3)), tol=1e-3, what='epilogue sumsq')
+    # data gradient: the same kernel on dy, weights read transposed + flipped from the forward tensor
+    dy = q(rand(6, (n, Co, H, W)))
+    dyd = dev(dy.to(torch.bfloat16) if bf else dy)
+    dref_q = F.conv_transpose2d(rb(dy), rb(Wt), padding=1)
+    for obf in ((0, 1) if bf else (0,)):
+        dcat = torch.empty(n, Ci, H, W, device='cuda', dtype=torch.bfloat16 if obf else torch.float32)
+        L.call('mo_conv3x3_fwd', L.ptr(dyd), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wd_), Ci,
+               n, H, W, L.ptr(dcat), Ci * H * W, None, L.BF_MATH | L.W_FLIP | (L.BF_IN0 * bf) | (L.BF_OUT * obf), L.stream())
+        close(dcat.float(), dref_q, tol=4e-3 if obf else 1e-4, what='conv bwd data vs bf16-rounded operands')
+
+
 @pytest.mark.parametrize('n,gs,C,H,W,pool,use_da', [(6, 3, 4, 16, 16, True, True), (4, 2, 8, 8, 8, True, False),
                                                     (4, 1, 16, 8, 12, False, True), (2, 2, 64, 8, 8, False, True)])
 @pytest.mark.parametrize('bf', [0, 1])
