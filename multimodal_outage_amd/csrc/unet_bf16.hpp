@@ -304,3 +304,218 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix pipe (ub_wgrad3x3_kernel):
+//   dW[co][(ci,ky),kx] = sum_{img,pixel} dy[co][pixel] * act(x)[ci][pixel + (ky-1, kx-1)]
+//   D[m = (ci,ky)][n = co] += A[m][k] * B[k][n],   k = 32 consecutive pixels of an image row, one MFMA per kx:
+//   * B: a lane's 8 consecutive pixels of dy[co] are 16 contiguous bytes of the NCHW tensor -- loaded straight from
+//     global memory into the fragment register (no LDS), one stage ahead;
+//   * A: the activated input tile lies in LDS PLANAR as bf16 ([ci][row][col], as in HBM); a lane reads the 16 aligned
+//     bytes of its 8 pixels plus the dword on either side and forms the kx = 0 / 1 / 2 fragments with v_alignbit
+//     (the shift by one pixel is a 16-bit funnel shift; all lanes of an MFMA share kx, so the shift is a constant);
+//   * the four waves of a workgroup split the tile's pixels (k), each keeps the whole D in registers over every image
+//     of its range; one fold at the end, slab rows as for uw_wgrad_mfma_kernel (summed by uslab_reduce_kernel).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ub_align16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+
+template <int CI, int NB, int RB, bool TWO>    // padded input channels, blocks of 16 output channels, rows per stage, two views
+__global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
+  constexpr int TW = UB_TW, TH = UB_TH, LDW = TW + 16;    // col = x - x0 + 8 (interior 16-byte aligned; x0-4 .. x0+TW+3 staged)
+  constexpr int NR = RB + 2, QH = TW / 4 + 2;
+  constexpr int PS = NR * LDW + 8;                        // plane stride (elements)
+  constexpr int CS = TWO ? CI / 2 : CI;                   // channels per view
+  constexpr int TPP = 2 * NR * QH;                        // staging tasks (4 pixels of one channel) per channel pair
+  constexpr int NP = (TPP + 255) / 256;                   // ... per thread
+  constexpr int NCP = CS / 2;                             // channel pairs per view
+  constexpr int NTV = NCP * NP;                           // tasks per thread and view
+  constexpr int NV = TWO ? 2 : 1;
+  constexpr int NPAIR = CI * 3;                           // rows of D: (ci, ky)
+  constexpr int NJ = (NPAIR + 15) / 16;
+  constexpr int KS = RB / 2;                              // k steps (32 pixels) per wave and stage
+  constexpr int NBI = TH / RB;
+  constexpr int XS_BYTES = CI * PS * 2, FOLD_BYTES = NJ * 3 * NB * 1024;
+  __shared__ __attribute__((aligned(16))) char smem[XS_BYTES > FOLD_BYTES ? XS_BYTES : FOLD_BYTES];
+  unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
+  float* fold = reinterpret_cast<float*>(smem);            // (after the last stage)
+  __shared__ float aff[2][CI];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
+  const int tiles_x = a.Wd / TW;
+  const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
+  const int Ci = a.C0 + a.C1;
+  const int HW = a.H * a.Wd;
+
+  // staging pattern of one channel pair (the same for every pair, view, image and stage)
+  int toff[NP], tdst[NP], trow[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int idx = tid + p * 256;
+    const int cl = idx / (NR * QH), r2 = idx - cl * (NR * QH), r = r2 / QH, q = r2 - r * QH;
+    const int x = x0 + 4 * q - 4;
+    toff[p] = (cl * a.H + y0 + r - 1) * a.Wd + x;
+    tdst[p] = (idx < TPP) ? cl * PS + r * LDW + 4 * q + 4 : -1;
+    trow[p] = (idx < TPP && (unsigned)x < (unsigned)a.Wd) ? y0 + r - 1 : -(1 << 24);
+  }
+  // A fragments: LDS byte address of this lane's 8 pixels (kx = 1) in the first row / half of the wave
+  int abase[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int pi = min(j * 16 + lp, NPAIR - 1), ci = pi / 3, ky = pi - 3 * ci;
+    abase[j] = (ci * PS + (wave * (RB / 4) + ky) * LDW + 8 * lg + 8) * 2;
+  }
+  // B fragments: element offset of this lane's 8 pixels of dy[co] in the first row / half of the wave
+  unsigned dyo[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    dyo[nb] = (nb * 16 + lp < a.Co) ? (unsigned)((((nb * 16 + lp) * a.H + y0 + wave * (RB / 4)) * a.Wd + x0 + 8 * lg) * 2) : UB_OOB;
+
+  ub_f4 acc[NJ][3][NB];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[j][kx][nb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
+
+  const long img0 = (long)blockIdx.y * a.img_per_wg;
+  const long img1 = min(img0 + (long)a.img_per_wg, a.n_img);
+  const int nstage = (int)(img1 - img0) * NBI;
+  ub_u4 raw[NV * NTV];                                    // (bf16 views use two dwords of each)
+  ub_u4 dyr[KS][NB];
+
+  auto load_view = [&](auto bfc, const int sec, const long img, const int b) {
+    constexpr bool BF = decltype(bfc)::value;
+    constexpr int es = BF ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t rs = sec ? ub_rsrc(reinterpret_cast<const char*>(a.in1) + img * a.is1 * es, (long)a.C1 * HW * es)
+                                          : ub_rsrc(reinterpret_cast<const char*>(a.in0) + img * a.is0 * es, (long)a.C0 * HW * es);
+#pragma unroll
+    for (int cp = 0; cp < NCP; ++cp)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned off = (unsigned)((toff[p] + cp * 2 * HW + b * RB * a.Wd) * es);
+        ub_u4& d = raw[sec * NTV + cp * NP + p];
+        if (BF) { const ub_u2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0); d[0] = u[0]; d[1] = u[1]; }
+        else d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+      }
+  };
+  auto issue_loads = [&](const int k) {
+    const long img = img0 + k / NBI;
+    const int b = k % NBI;
+    if (a.bf0) load_view(UbBool<true>{}, 0, img, b); else load_view(UbBool<false>{}, 0, img, b);
+    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, 1, img, b); else load_view(UbBool<false>{}, 1, img, b); }
+    const __amdgpu_buffer_rsrc_t rd = ub_rsrc(reinterpret_cast<const char*>(a.dy) + img * a.dys * 2, (long)a.Co * HW * 2);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        dyr[s][nb] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)(dyo[nb] + (unsigned)(((b * RB + (s >> 1)) * a.Wd + 32 * (s & 1)) * 2)), 0, 0);
+  };
+  auto commit_view = [&](auto bfc, const int sec, const int b) {
+    constexpr bool BF = decltype(bfc)::value;
+    const float flo = (sec ? a.relu1 : a.relu0) ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int cp = 0; cp < NCP; ++cp)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int cbase = sec * CS + cp * 2;
+        const int dst = tdst[p] + cbase * PS;
+        const int ch = cbase + ((tdst[p] >= PS) ? 1 : 0);
+        const float keep = ((unsigned)(trow[p] + b * RB) < (unsigned)a.H) ? 1.f : 0.f;
+        const float s_ = aff[0][ch] * keep, t_ = aff[1][ch] * keep;
+        const ub_u4& d = raw[sec * NTV + cp * NP + p];
+        const unsigned ux = d[0], uy = d[1];
+        float4 v;
+        if (BF) v = make_float4(ua_lo(ux), ua_hi(ux), ua_lo(uy), ua_hi(uy));
+        else { const unsigned uz = d[2], uw = d[3];
+               v = make_float4(__uint_as_float(ux), __uint_as_float(uy), __uint_as_float(uz), __uint_as_float(uw)); }
+        v.x = fmaxf(v.x * s_ + t_, flo); v.y = fmaxf(v.y * s_ + t_, flo);
+        v.z = fmaxf(v.z * s_ + t_, flo); v.w = fmaxf(v.w * s_ + t_, flo);
+        if (tdst[p] >= 0) *reinterpret_cast<uint2*>(&xs[dst]) = make_uint2(ub_pack2(v.x, v.y), ub_pack2(v.z, v.w));
+      }
+  };
+  auto load_affine = [&](const long img) {
+    if (tid < CI) {
+      const long grp = img / a.gsize;
+      float s_ = 0.f, t_ = 0.f;
+      const bool sec = TWO && tid >= CS;
+      const int cc = sec ? tid - CS : tid;
+      if (cc < (sec ? a.C1 : a.C0)) {
+        const float* sc = sec ? a.sc1 : a.sc0;
+        const float* sh = sec ? a.sh1 : a.sh0;
+        const long gi = grp * (sec ? a.C1 : a.C0) + cc;
+        s_ = sc ? sc[gi] : 1.f; t_ = sc ? sh[gi] : 0.f;
+      }
+      aff[0][tid] = s_; aff[1][tid] = t_;
+    }
+  };
+
+  if (nstage > 0) { load_affine(img0); issue_loads(0); }
+#pragma unroll 1
+  for (int k = 0; k < nstage; ++k) {
+    const long img = img0 + k / NBI;
+    const int b = k % NBI;
+    __syncthreads();                                      // stage k-1's matrix phase is done with the tile; aff is in place
+    if (a.bf0) commit_view(UbBool<true>{}, 0, b); else commit_view(UbBool<false>{}, 0, b);
+    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, 1, b); else commit_view(UbBool<false>{}, 1, b); }
+    ub_u4 dyc[KS][NB];                                    // this stage's dy fragments (the registers are refilled below)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) dyc[s][nb] = dyr[s][nb];
+    __syncthreads();
+    if (k + 1 < nstage) {
+      issue_loads(k + 1);
+      if (b == NBI - 1 && (img + 1) % a.gsize == 0) load_affine(img + 1);
+    }
+    const char* lds = reinterpret_cast<const char*>(xs);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      ub_bf8 bfr[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bfr[nb] = __builtin_bit_cast(ub_bf8, dyc[s][nb]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const char* ap = lds + abase[j] + ((s >> 1) * LDW + 32 * (s & 1)) * 2;
+        const unsigned dm = *reinterpret_cast<const unsigned*>(ap - 4);
+        const uint4 dc = *reinterpret_cast<const uint4*>(ap);
+        const unsigned dn = *reinterpret_cast<const unsigned*>(ap + 16);
+        const ub_u4 f0 = {ub_align16(dc.x, dm), ub_align16(dc.y, dc.x), ub_align16(dc.z, dc.y), ub_align16(dc.w, dc.z)};
+        const ub_u4 f1 = {dc.x, dc.y, dc.z, dc.w};
+        const ub_u4 f2 = {ub_align16(dc.y, dc.x), ub_align16(dc.z, dc.y), ub_align16(dc.w, dc.z), ub_align16(dn, dc.w)};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc[j][0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ub_bf8, f0), bfr[nb], acc[j][0][nb], 0, 0, 0);
+          acc[j][1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ub_bf8, f1), bfr[nb], acc[j][1][nb], 0, 0, 0);
+          acc[j][2][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ub_bf8, f2), bfr[nb], acc[j][2][nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // fold the four waves in a fixed order (wave 0 stores, 1..3 add in turn) and write this workgroup's slab row
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            float4* f = reinterpret_cast<float4*>(&fold[(((j * 3 + kx) * NB + nb) * 64 + lane) * 4]);
+            float4 v = make_float4(acc[j][kx][nb][0], acc[j][kx][nb][1], acc[j][kx][nb][2], acc[j][kx][nb][3]);
+            if (w > 0) { const float4 o = *f; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *f = v;
+          }
+    }
+  }
+  __syncthreads();
+  const long z = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  float* row = a.slab + z * ((long)a.Co * Ci * 9);
+  for (int e = tid; e < NJ * 3 * NB * 256; e += 256) {
+    const int blk = e >> 8, l = (e >> 2) & 63, r = e & 3;
+    const int nb = blk % NB, kx = (blk / NB) % 3, j = blk / (3 * NB);
+    const int co = nb * 16 + (l & 15), pi = j * 16 + (l >> 4) * 4 + r;
+    const int ci = pi / 3, ky = pi - 3 * ci;
+    if (co < a.Co && ci < Ci) row[((long)co * Ci + ci) * 9 + ky * 3 + kx] = fold[e];
+  }
+}

@@ -319,11 +319,42 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
                                      long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
                                      long n_img, int H, int Wd, float* dW, float* ws, int dtypes, void* stream) {
   MO_CHECK_ARG(dy && in0 && dW && ws && C0 > 0 && C1 >= 0 && Co > 0 && n_img > 0 && (Wd % 4) == 0);
-  dtypes &= ~MO_BF_MATH;                              // (no bf16 matrix-pipe weight gradient yet: fp32 arithmetic)
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31));
   const int Ci = C0 + C1;
   const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
+  if ((dtypes & MO_BF_MATH) && (dtypes & MO_BF_DY) && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 7) == 0 &&
+      Co <= 16 && (C1 == 0 || (C0 == C1 && (C0 == 4 || C0 == 8 || C0 == 16))) && mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) {
+    // bf16 matrix pipe (unet_bf16.hpp): one slab row per (tile position, image range)
+    const long tiles = (long)(Wd / UB_TW) * (H / UB_TH);
+    const long max_rows = ((long)Co * Ci * 9 <= UW_THIN_ROW) ? UW_THIN_SLABS : UD_MAX_SLABS;
+    long ipw = (n_img * tiles + 1023) / 1024;
+    if (ipw * 1 < (n_img * tiles + max_rows - 1) / max_rows) ipw = (n_img * tiles + max_rows - 1) / max_rows;
+    if (ipw < 1) ipw = 1;
+    const long nchunk = (n_img + ipw - 1) / ipw;
+    if (tiles * nchunk <= max_rows && nchunk < 65536) {
+      UdWgradArgs a;
+      a.dy = dy; a.dys = dystride;
+      a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
+      a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
+      a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+      a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = 1;
+      a.bfd = 1; a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0;
+      dim3 grid((unsigned)tiles, (unsigned)nchunk);
+      hipStream_t st = ST(stream);
+      const bool two = C1 > 0;
+#define UBW(CI, NB, RB, TWO) hipLaunchKernelGGL((ub_wgrad3x3_kernel<CI, NB, RB, TWO>), grid, dim3(256), 0, st, a)
+      if (Ci <= 4) UBW(4, 1, 16, false);
+      else if (Ci <= 8) { if (two) UBW(8, 1, 16, true); else UBW(8, 1, 16, false); }
+      else if (Ci <= 16) { if (two) UBW(16, 1, 8, true); else UBW(16, 1, 8, false); }
+      else { if (two) UBW(32, 1, 4, true); else UBW(32, 1, 4, false); }
+#undef UBW
+      const long nw = (long)Co * Ci * 9;
+      hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(nw, 32)), dim3(1024), 0, st, ws, nw, (int)(tiles * nchunk), dW, nw);
+      return mo_launch_status();
+    }
+  }
+  dtypes &= ~MO_BF_MATH;                              // the fp32 kernels serve the request with fp32 arithmetic
   const int uwt = ((Wd % 64) == 0 && (H % 8) == 0) ? 64 : ((Wd % 32) == 0 && (H % 16) == 0) ? 32
                   : ((Wd % 16) == 0 && (H % 32) == 0) ? 16 : 0;
   if (Co <= 32 && uwt && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 3) == 0 &&

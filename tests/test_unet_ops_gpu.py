@@ -141,6 +141,15 @@ def test_conv3x3_bf16_matrix_pipe(L, n, gs, C0, C1, Co, H, W, bf):
         L.call('mo_conv3x3_fwd', L.ptr(dyd), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wd_), Ci,
                n, H, W, L.ptr(dcat), Ci * H * W, None, L.BF_MATH | L.W_FLIP | (L.BF_IN0 * bf) | (L.BF_OUT * obf), L.stream())
         close(dcat.float(), dref_q, tol=4e-3 if obf else 1e-4, what='conv bwd data vs bf16-rounded operands')
+    if bf and Co <= 16:
+        # weight gradient: dy read straight into the B fragments, the activated input planar in LDS
+        Wp = Wt.clone().requires_grad_(True)
+        F.conv2d(rb(cat), Wp, None, padding=1).backward(rb(dy))
+        dW = torch.full((Co, Ci, 3, 3), float('nan'), device='cuda')
+        ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * H * W), device='cuda')
+        L.call('mo_conv3x3_bwd_weight', L.ptr(dyd), Co * H * W, Co, *args_in, gs, n, H, W, L.ptr(dW), L.ptr(ws),
+               L.BF_MATH | L.BF_DY | L.BF_IN0, L.stream())
+        close(dW, Wp.grad, tol=1e-3, what='conv dW vs bf16-rounded operands')
 
 
 @pytest.mark.parametrize('n,gs,C,H,W,pool,use_da', [(6, 3, 4, 16, 16, True, True), (4, 2, 8, 8, 8, True, False),
