@@ -1207,8 +1207,63 @@ extern "C" int mo_spmm_blk(const int32_t* rowptr, const int32_t* lcol, const flo
   return mo_launch_status();
 }
 
+// Small graphs (N <= 128: the 67-county Graph WaveNet inside Modified_UNET): the node-axis products are a few MFLOP, and
+// a 128x128 tile-engine launch spends ~30 us on one padded tile row.  Direct kernels instead:
+//   Y[m][j] (+)= sum_k A[k][m] * X[k][j]: one wave per output row and 256 columns, operands straight from L2;
+//   dA[v][w] (+)= sum_j X[v][j] * dY[w][j]: a workgroup owns a 16 x 16 block of dA and walks j in panels of 64.
+#define ADJS_MAXN 128
+// one wave = one output row m x 256 columns (a float4 per lane): A[k][m] is a scalar load, X[k][j..j+3] a coalesced
+// 16-byte load from L2; no LDS, no barrier.  J % 4 == 0.
+__global__ __launch_bounds__(256) void adj_small_kernel(const float* __restrict__ A, int N, const float* __restrict__ X,
+                                                        float* __restrict__ Y, long J, int beta) {
+  const int lane = threadIdx.x & 63;
+  const int m = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+  const long j = ((long)blockIdx.x * 64 + lane) * 4;
+  if (m >= N || j >= J) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* xp = X + j;
+  const float* ap = A + m;
+#pragma unroll 8
+  for (int k = 0; k < N; ++k) {
+    const float a = ap[(long)k * N];
+    const float4 x = *reinterpret_cast<const float4*>(xp + (long)k * J);
+    acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y); acc.z = fmaf(a, x.z, acc.z); acc.w = fmaf(a, x.w, acc.w);
+  }
+  float4* y = reinterpret_cast<float4*>(Y + (long)m * J + j);
+  if (beta) { const float4 o = *y; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+  *y = acc;
+}
+__global__ __launch_bounds__(256) void adj_grad_small_kernel(const float* __restrict__ X, const float* __restrict__ dY, int N,
+                                                             long J, float* __restrict__ dA, int beta) {
+  __shared__ float xs[16][65], ys[16][65];
+  const int tid = threadIdx.x, tw = tid & 15, tv = tid >> 4;
+  const int v0 = blockIdx.y * 16, w0 = blockIdx.x * 16;
+  float acc = 0.f;
+  for (long jc = 0; jc < J; jc += 64) {
+    __syncthreads();
+    for (int i = tid; i < 16 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const bool jin = jc + c < J;
+      xs[r][c] = (jin && v0 + r < N) ? X[(long)(v0 + r) * J + jc + c] : 0.f;
+      ys[r][c] = (jin && w0 + r < N) ? dY[(long)(w0 + r) * J + jc + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int c = 0; c < 64; ++c) acc = fmaf(xs[tv][c], ys[tw][c], acc);
+  }
+  if (v0 + tv < N && w0 + tw < N) {
+    float* d = dA + (long)(v0 + tv) * N + w0 + tw;
+    *d = beta ? *d + acc : acc;
+  }
+}
+
 extern "C" int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, long J, int beta, void* stream) {
   MO_CHECK_ARG(A_km && X && Y && N > 0 && J > 0 && J < (1L << 31));
+  if (N <= ADJS_MAXN && (J & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)Y)) & 15) == 0) {
+    hipLaunchKernelGGL(adj_small_kernel, dim3((unsigned)mo_cdiv(J, 256), (unsigned)mo_cdiv(N, 4)), dim3(256), 0, ST(stream),
+                       A_km, N, X, Y, J, beta);
+    return mo_launch_status();
+  }
   MoOperand A = op_simple(A_km, N, N, N);        // KROWS: rows = k, cols = m
   MoOperand Bo = op_simple(X, (int)J, N, J);     // KROWS: rows = k, cols = n = j
   MoEpi E; epi_init(E, Y, (int)J);
@@ -1218,6 +1273,10 @@ extern "C" int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, l
 
 extern "C" int mo_adj_grad(const float* X, const float* dY, int N, long J, float* dA, int beta, void* stream) {
   MO_CHECK_ARG(X && dY && dA && N > 0 && J > 0 && J < (1L << 31));
+  if (N <= ADJS_MAXN) {
+    hipLaunchKernelGGL(adj_grad_small_kernel, dim3(mo_cdiv(N, 16), mo_cdiv(N, 16)), dim3(256), 0, ST(stream), X, dY, N, J, dA, beta);
+    return mo_launch_status();
+  }
   MoOperand A = op_simple(X, (int)J, N, J);      // XROWS: rows = m = v, cols = k = j
   MoOperand Bo = op_simple(dY, (int)J, N, J);    // XROWS: rows = n = w, cols = k = j
   MoEpi E; epi_init(E, dA, N);

@@ -200,8 +200,8 @@ class Modified_UNET(nn.Module):
         named = dict(self.named_parameters())
         # optional {parameter name: preallocated gradient tensor} of a flat-buffer trainer (FlatTrainer.attach): the
         # engine then writes the UNet-side gradients in place instead of handing new tensors to autograd.  The
-        # Graph-WaveNet inside is called once per batch element (unet.py:221), so its gradients must accumulate
-        # through autograd and are not registered here.
+        # Graph-WaveNet inside is called once per batch element (unet.py:221): with B > 1 its gradients must accumulate
+        # through autograd.
         state = dict(gsize=H, training=self.training, bufs=self._bufs(),
                      fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None),
                      act_dtype=getattr(self, 'act_dtype', 'f32'))
@@ -212,6 +212,8 @@ class Modified_UNET(nn.Module):
         feat, fms = outs[0], outs[1:]
         feat = feat.view(B, NC, H, feature_vector_size)
         zs = []
+        # (a single call per backward pass may write its gradients in place; several must accumulate through autograd)
+        self.st_gnn._mo_grad_out = getattr(self, '_mo_grad_out_st_gnn', None) if B == 1 else None
         for b in range(B):                                       # unet.py:221: one gwnet call per batch element
             o = torch.cat((feat[b], time_dim[b].to(feat.dtype)), dim=-1)      # (67, H, 320)  unet.py:224
             zs.append(self.st_gnn(o))                            # (67, H, 256)

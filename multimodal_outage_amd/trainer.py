@@ -122,6 +122,10 @@ class FlatTrainer:
             m._mo_grad_ready = self.ready_callback()
         elif isinstance(m, Modified_UNET):
             m._mo_grad_out = {k: v for k, v in self.grad_views.items() if not k.startswith('st_gnn.')}
+            # the inner Graph WaveNet is called once per batch element (unet.py:221): Modified_UNET.forward hands it these
+            # views only for a batch of one window (82 AccumulateGrad adds per step otherwise); with more windows its
+            # gradients accumulate through autograd
+            m._mo_grad_out_st_gnn = self.grad_out('st_gnn.')
         return self
 
     def zero_grad(self):

@@ -130,14 +130,16 @@ def test_modified_unet_bf16_storage_mode(name, B, channels, size, seed):
     assert all(torch.isfinite(v.grad).all() for v in m.parameters() if v.grad is not None)
 
 
-def test_flat_trainer_attach_writes_the_same_gradients():
+@pytest.mark.parametrize('B', [1, 2])
+def test_flat_trainer_attach_writes_the_same_gradients(B):
     """FlatTrainer.attach(): the UNet-side Functions write their gradients straight into the flat gradient buffer (no
     AccumulateGrad kernels) -- the result must be bit-identical to the gradients autograd accumulates without it, the
-    Graph WaveNet inside (called once per batch element, unet.py:221) still accumulating through autograd."""
+    Graph WaveNet inside (called once per batch element, unet.py:221) accumulating through autograd for B = 2 and
+    writing in place for B = 1."""
     from multimodal_outage_amd.trainer import FlatTrainer
-    x = rand(401, (2, 67, 2, 1, 128, 128)).cuda()
-    tdim = rand(403, (2, 67, 2, 64)).cuda()
-    tgt = rand(402, (2, 67, 2, 1, 128, 128)).cuda()
+    x = rand(401, (B, 67, 2, 1, 128, 128)).cuda()
+    tdim = rand(403, (B, 67, 2, 64)).cuda()
+    tgt = rand(402, (B, 67, 2, 1, 128, 128)).cuda()
     got = {}
     for mode in ('autograd', 'attach'):
         m = _model().train()
