@@ -224,6 +224,13 @@ int mo_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
 #define MO_BF_OUT 4   /* the output tensor (mo_unet_act_bwd: dy) */
 #define MO_BF_DY 8    /* the output-gradient operand of a weight / data gradient */
 #define MO_BF_DP 16   /* mo_unet_act_bwd: the pooled gradient dp */
+/* Arithmetic of the bf16 mode: with MO_BF_MATH the 3x3 convs, their data and weight gradients run on the bf16 matrix pipe
+ * (operands rounded to bf16 on the way into the MFMA, fp32 accumulation) where csrc/unet_bf16.hpp has a kernel for the
+ * shape (mo_conv3x3_bf16_route); elsewhere the flag is ignored and the arithmetic is fp32.  MO_W_FLIP (with MO_BF_MATH,
+ * mo_conv3x3_fwd only): W is the forward conv's (Ci, Co, 3, 3) tensor and is read transposed + flipped -- the data
+ * gradient without a flipped copy. */
+#define MO_BF_MATH 32
+#define MO_W_FLIP 64
 
 /* DoubleConv conv (unet.py:44,47; nn.Conv2d k=3 pad=1 bias=False) over the channel concat of up to two
  * activated views (the skip/up cat of unet.py:83): out[img][co] raw. W: (Co, C0+C1, 3, 3). */
@@ -235,6 +242,10 @@ int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, co
                    int dtypes /* MO_BF_IN0 | MO_BF_IN1 | MO_BF_OUT */, void* stream);
 /* per-image statistics rows mo_conv3x3_fwd writes for this shape (0: none -- run mo_nchw_stats on the output) */
 int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
+/* ... when the call carries `dtypes` (MO_BF_MATH routes to the bf16 matrix-pipe kernel, whose tiles are 16 x 64) */
+int mo_conv3x3_stats_tiles2(int Ci, int Co, long n_img, int H, int Wd, int dtypes);
+/* 1 when the bf16 matrix-pipe kernels (csrc/unet_bf16.hpp) serve a 3x3 conv of this shape under MO_BF_MATH */
+int mo_conv3x3_bf16_route(int Ci, int Co, long n_img, int H, int Wd);
 /* Wf[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]; the data gradient is mo_conv3x3_fwd(dy, Wf). */
 int mo_conv3x3_flip_weights(const float* W, int Co, int Ci, float* Wf, void* stream);
 long mo_unet_wgrad_ws_floats(int M, int N, long P);
@@ -273,6 +284,11 @@ int mo_group_bn_finalize(const float* stats /* [n_img][ntile][C][2] */, long n_i
                          const float* beta, float* running_mean, float* running_var, float momentum,
                          float eps, int training, float* scale, float* shift, float* mean, float* rstd,
                          void* stream);
+/* the same in one launch (train mode: one workgroup does both stages); num_batches_tracked (int64, may be NULL) += G */
+int mo_group_bn_finalize2(const float* stats, long n_img, int C, int gsize, int HW, int ntile, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          int training, float* scale, float* shift, float* mean, float* rstd,
+                          long long* num_batches_tracked, void* stream);
 /* materialise relu(y*sc+sh), optionally 2x2 max-pooled (Down, unet.py:60) */
 int mo_unet_act(const float* y, long istride, int C, long n_img, int H, int Wd, const float* sc,
                 const float* sh, int gsize, int pool, float* out, long ostride,

@@ -81,6 +81,7 @@ SIGNATURES = {
     'mo_convt2x2_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp]),
     'mo_nchw_stats': (i32, [vp, i64, i32, i64, i32, vp, vp]),
     'mo_group_bn_finalize': (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
+    'mo_group_bn_finalize2': (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp]),
     'mo_unet_act': (i32, [vp, i64, i32, i64, i32, i32, vp, vp, i32, i32, vp, i64, i32, vp]),
     'mo_unet_act_bwd_ws_floats': (i64, [i64, i32]),
     'mo_unet_act_bwd': (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64,

@@ -675,20 +675,81 @@ __global__ void group_bn_running_kernel(const float* __restrict__ mean_g, const 
   }
   running_mean[c] = rm; running_var[c] = rv;
 }
+__global__ void counter_add_kernel(long long* p, long long v) { *p += v; }
+// both stages in ONE workgroup (train mode, G*C pairs walked by 1024 threads, then one thread per channel for the sequential
+// running-stat chain) + num_batches_tracked += G: three launches of 5..27 us per BatchNorm layer were one dependent chain
+__global__ __launch_bounds__(1024) void group_bn_fused_kernel(const float* __restrict__ stats, long G, int C, int gsize,
+                                                              int HW, int ntile, const float* gamma, const float* beta,
+                                                              float* running_mean, float* running_var, float momentum,
+                                                              float eps, float* scale, float* shift, float* mean_out,
+                                                              float* rstd_out, long long* nbt) {
+  extern __shared__ float mv[];                                    // [2][G*C]: mean, biased variance of every group
+  const double M = (double)gsize * HW;
+  const long rows = (long)gsize * ntile;
+  for (long i = threadIdx.x; i < G * C; i += 1024) {
+    const long g = i / C; const int c = (int)(i - g * C);
+    const float* st = stats + (g * rows * C + c) * 2;              // rows (image, tile) of the group are consecutive
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+    long j = 0;
+    for (; j + 1 < rows; j += 2) {
+      const float2 u = *reinterpret_cast<const float2*>(st + j * C * 2);
+      const float2 w = *reinterpret_cast<const float2*>(st + (j + 1) * C * 2);
+      a1 += u.x; a2 += u.y; b1 += w.x; b2 += w.y;
+    }
+    if (j < rows) { const float2 u = *reinterpret_cast<const float2*>(st + j * C * 2); a1 += u.x; a2 += u.y; }
+    const double s1 = a1 + b1, s2 = a2 + b2;
+    double m = s1 / M, v = s2 / M - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, var = (float)v;
+    const float rstd = 1.f / sqrtf(var + eps);
+    scale[i] = gamma[c] * rstd;
+    shift[i] = beta[c] - mean * gamma[c] * rstd;
+    mean_out[i] = mean;
+    rstd_out[i] = rstd;
+    mv[i] = mean; mv[G * C + i] = var;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && nbt) *nbt += G;
+  const int c = threadIdx.x;
+  if (c < C) {
+    const float unb = (M > 1.0) ? (float)(M / (M - 1.0)) : 1.f;
+    float rm = running_mean[c], rv = running_var[c];
+    for (long g = 0; g < G; ++g) {
+      const float mean = mv[g * C + c], var = mv[G * C + g * C + c];
+      rm = (1.f - momentum) * rm + momentum * mean;
+      rv = (1.f - momentum) * rv + momentum * (var * unb);
+    }
+    running_mean[c] = rm; running_var[c] = rv;
+  }
+}
+extern "C" int mo_group_bn_finalize2(const float* stats, long n_img, int C, int gsize, int HW, int ntile,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, int training, float* scale, float* shift, float* mean,
+                                     float* rstd, long long* num_batches_tracked, void* stream) {
+  MO_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && mean && rstd);
+  MO_CHECK_ARG(C > 0 && gsize > 0 && n_img > 0 && (n_img % gsize) == 0 && (!training || stats) && ntile >= 1);
+  const long G = n_img / gsize;
+  if (training && C <= 1024 && G * C <= 6144 && (((uintptr_t)stats) & 7) == 0) {
+    hipLaunchKernelGGL(group_bn_fused_kernel, dim3(1), dim3(1024), (size_t)G * C * 8, ST(stream), stats, G, C, gsize, HW, ntile, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, mean, rstd, num_batches_tracked);
+    return mo_launch_status();
+  }
+  hipLaunchKernelGGL(group_bn_stats_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, ST(stream), stats, G, C, gsize, HW,
+                     ntile, gamma, beta, running_mean, running_var, eps, training, scale, shift, mean, rstd);
+  if (training) {
+    hipLaunchKernelGGL(group_bn_running_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, ST(stream), mean, rstd, G, C, gsize,
+                       HW, momentum, eps, running_mean, running_var);
+    if (num_batches_tracked) hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ST(stream), num_batches_tracked, (long long)G);
+  }
+  return mo_launch_status();
+}
 extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int gsize, int HW, int ntile,
                                     const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float momentum,
                                     float eps, int training, float* scale, float* shift, float* mean, float* rstd,
                                     void* stream) {
-  MO_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && mean && rstd);
-  MO_CHECK_ARG(C > 0 && gsize > 0 && n_img > 0 && (n_img % gsize) == 0 && (!training || stats) && ntile >= 1);
-  const long G = n_img / gsize;
-  hipLaunchKernelGGL(group_bn_stats_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, ST(stream), stats, G, C, gsize, HW,
-                     ntile, gamma, beta, running_mean, running_var, eps, training, scale, shift, mean, rstd);
-  if (training)
-    hipLaunchKernelGGL(group_bn_running_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, ST(stream), mean, rstd, G, C, gsize,
-                       HW, momentum, eps, running_mean, running_var);
-  return mo_launch_status();
+  return mo_group_bn_finalize2(stats, n_img, C, gsize, HW, ntile, gamma, beta, running_mean, running_var, momentum, eps,
+                               training, scale, shift, mean, rstd, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -860,6 +921,39 @@ __global__ void unet_act_bwd_param_kernel(const double* __restrict__ k12, long G
   for (long g = 0; g < G; ++g) { db += k12[(g * C + c) * 2]; dg += k12[(g * C + c) * 2 + 1]; }
   dgamma[c] = (float)(dg * M); dbeta[c] = (float)(db * M);
 }
+// final + param in one workgroup (two dependent 5..16 us launches per layer before)
+__global__ __launch_bounds__(1024) void unet_act_bwd_final_param_kernel(const double* __restrict__ part, long G, int C,
+                                                                        int gsize, int HW, double* __restrict__ k12,
+                                                                        float* dgamma, float* dbeta) {
+  const double M = (double)gsize * HW;
+  for (long i = threadIdx.x; i < G * C; i += 1024) {
+    const long g = i / C; const int c = (int)(i - g * C);
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < gsize; ++j) {
+      const double* p = part + ((g * gsize + j) * C + c) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+    k12[i * 2] = s1 / M;
+    k12[i * 2 + 1] = s2 / M;
+  }
+  __threadfence();
+  __syncthreads();
+  // per channel: 4 threads x G/4 groups each, folded in a fixed order
+  const int c = threadIdx.x >> 2, sub = threadIdx.x & 3;
+  __shared__ double red[1024][2];
+  double dg = 0.0, db = 0.0;
+  if (c < C) {
+    const volatile double* kv = k12;                               // (written by this workgroup above)
+    for (long g = sub; g < G; g += 4) { db += kv[(g * C + c) * 2]; dg += kv[(g * C + c) * 2 + 1]; }
+  }
+  red[threadIdx.x][0] = dg; red[threadIdx.x][1] = db;
+  __syncthreads();
+  if (c < C && sub == 0) {
+    const int t = threadIdx.x;
+    dgamma[c] = (float)(((red[t][0] + red[t + 1][0]) + (red[t + 2][0] + red[t + 3][0])) * M);
+    dbeta[c] = (float)(((red[t][1] + red[t + 1][1]) + (red[t + 2][1] + red[t + 3][1])) * M);
+  }
+}
 __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, const float* __restrict__ sc,
@@ -910,8 +1004,12 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img), dim3(HW >= 1024 ? 256 : 64), 0, st, y, istride,
                      C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part, fl);
   const long G = n_img / gsize;
-  hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, k12);
-  hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
+  if (C <= 256 && G * C <= 65536) {
+    hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(1), dim3(1024), 0, st, part, G, C, gsize, HW, k12, dgamma, dbeta);
+  } else {
+    hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, k12);
+    hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
+  }
   const long total4 = n_img * C * (HW / 4);
   hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total4, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
                      gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4, fl);

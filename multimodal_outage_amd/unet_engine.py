@@ -90,11 +90,10 @@ def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev, out_bf=False
         stats = _empty(n, Co, 2, dev=dev)
         L.call('mo_nchw_stats', L.ptr(y), Co * H * W, Co, n, H * W, L.ptr(stats), st)
     rm, rv, nbt = bufs[bnkey]
-    L.call('mo_group_bn_finalize', L.ptr(stats), n, Co, gs, H * W, max(ntile, 1), L.ptr(p[bnkey + '.weight']),
+    # (train mode: statistics, folded affine, the G sequential running-stat updates and num_batches_tracked in one launch)
+    L.call('mo_group_bn_finalize2', L.ptr(stats), n, Co, gs, H * W, max(ntile, 1), L.ptr(p[bnkey + '.weight']),
            L.ptr(p[bnkey + '.bias']), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, 1 if training else 0,
-           L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(aff[2]), L.ptr(aff[3]), st)
-    if training:
-        nbt += G
+           L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(aff[2]), L.ptr(aff[3]), nbt.data_ptr() if training else None, st)
     return y, aff
 
 
