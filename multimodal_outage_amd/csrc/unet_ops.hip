@@ -882,7 +882,11 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
   const long dpoff = img * dpstride + (long)c * (H / 2) * (W / 2);
   const int Q = W >> 2;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < H * Q; i += blockDim.x) {
+  // a plane is cut into gridDim.z slices of whole quads (one partial row each): with 4 channels x 134 images a
+  // workgroup per plane left 2 workgroups per CU walking 64 dependent trips each
+  const int per = (H * Q + gridDim.z - 1) / gridDim.z;
+  const int i_end = min(H * Q, (int)(blockIdx.z + 1) * per);
+  for (int i = blockIdx.z * per + threadIdx.x; i < i_end; i += blockDim.x) {
     const int yy = i / Q, q = i - yy * Q;
     float4 yv; float dz[4];
     unet_dz4(y, yoff, W, yy, q, s, t, da, daoff, dp, dpoff, f, yv, dz);
@@ -896,17 +900,20 @@ __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long is
     if (threadIdx.x < k) { sm[0][threadIdx.x] += sm[0][threadIdx.x + k]; sm[1][threadIdx.x] += sm[1][threadIdx.x + k]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { part[(img * C + c) * 2] = sm[0][0]; part[(img * C + c) * 2 + 1] = sm[1][0]; }
+  if (threadIdx.x == 0) {
+    const long row = img * gridDim.z + blockIdx.z;
+    part[(row * C + c) * 2] = sm[0][0]; part[(row * C + c) * 2 + 1] = sm[1][0];
+  }
 }
-__global__ void unet_act_bwd_final_kernel(const double* __restrict__ part, long G, int C, int gsize, int HW,
+__global__ void unet_act_bwd_final_kernel(const double* __restrict__ part, long G, int C, int gsize, int HW, int S,
                                           double* __restrict__ k12 /* [G][C][2] */) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G * C) return;
   const long g = i / C; const int c = (int)(i - g * C);
   const double M = (double)gsize * HW;
   double s1 = 0.0, s2 = 0.0;
-  for (int j = 0; j < gsize; ++j) {
-    const double* p = part + ((g * gsize + j) * C + c) * 2;
+  for (int j = 0; j < gsize * S; ++j) {
+    const double* p = part + ((g * gsize * S + j) * C + c) * 2;
     s1 += p[0]; s2 += p[1];
   }
   k12[i * 2] = s1 / M;
@@ -923,14 +930,14 @@ __global__ void unet_act_bwd_param_kernel(const double* __restrict__ k12, long G
 }
 // final + param in one workgroup (two dependent 5..16 us launches per layer before)
 __global__ __launch_bounds__(1024) void unet_act_bwd_final_param_kernel(const double* __restrict__ part, long G, int C,
-                                                                        int gsize, int HW, double* __restrict__ k12,
+                                                                        int gsize, int HW, int S, double* __restrict__ k12,
                                                                         float* dgamma, float* dbeta) {
   const double M = (double)gsize * HW;
   for (long i = threadIdx.x; i < G * C; i += 1024) {
     const long g = i / C; const int c = (int)(i - g * C);
     double s1 = 0.0, s2 = 0.0;
-    for (int j = 0; j < gsize; ++j) {
-      const double* p = part + ((g * gsize + j) * C + c) * 2;
+    for (int j = 0; j < gsize * S; ++j) {
+      const double* p = part + ((g * gsize * S + j) * C + c) * 2;
       s1 += p[0]; s2 += p[1];
     }
     k12[i * 2] = s1 / M;
@@ -983,7 +990,8 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   o.w = gr * (float)((double)dz[3] - k1 - (double)((yv.w - mu) * rs) * k2);
   ua_st4(dy, img * dystride + ((long)c * H + yy) * W + 4 * q, o, f.dy);
 }
-extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * 8 + 64; }   // double partials + double k12
+#define UA_MAX_SLICES 16
+extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * (4 * UA_MAX_SLICES + 4) + 64; }   // double partials (<= 16 slices per plane) + double k12
 extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
                                const float* gamma, const float* mean, const float* rstd, const float* sc,
                                const float* sh, const float* da, long dastride, const float* dp, long dpstride,
@@ -998,16 +1006,21 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   hipStream_t st = ST(stream);
   const UaFlags fl = {(dtypes & MO_BF_IN0) != 0, (dtypes & MO_BF_IN1) != 0, (dtypes & MO_BF_DP) != 0, (dtypes & MO_BF_OUT) != 0};
   MO_CHECK_ARG((((uintptr_t)ws) & 7) == 0);
-  double* part = reinterpret_cast<double*>(ws);
-  double* k12 = part + n_img * C * 2;
   const int HW = H * Wd;
-  hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img), dim3(HW >= 1024 ? 256 : 64), 0, st, y, istride,
+  const int nthr = HW >= 1024 ? 256 : 64;
+  int S = (int)(4096 / ((long)C * n_img));                  // slices per plane: ~4096 workgroups, >= 4 trips per thread
+  if (S > HW / (16 * nthr)) S = HW / (16 * nthr);
+  if (S > UA_MAX_SLICES) S = UA_MAX_SLICES;
+  if (S < 1) S = 1;
+  double* part = reinterpret_cast<double*>(ws);
+  double* k12 = part + n_img * C * 2 * S;
+  hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img, S), dim3(nthr), 0, st, y, istride,
                      C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part, fl);
   const long G = n_img / gsize;
   if (C <= 256 && G * C <= 65536) {
-    hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(1), dim3(1024), 0, st, part, G, C, gsize, HW, k12, dgamma, dbeta);
+    hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(1), dim3(1024), 0, st, part, G, C, gsize, HW, S, k12, dgamma, dbeta);
   } else {
-    hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, k12);
+    hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, S, k12);
     hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
   }
   const long total4 = n_img * C * (HW / 4);
