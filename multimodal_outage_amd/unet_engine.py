@@ -7,9 +7,45 @@ per-county calls, and running stats receive the same sequential county-then-batc
 ``UnetDecodeFn`` (Decoder + Expansion); the skip feature maps travel between them as raw conv
 outputs whose "gradient" is defined as the gradient w.r.t. their activated view.
 """
+import os
+
 import torch
 
 from . import _lib as L
+
+WGRAD_LANE = os.environ.get('MO_UNET_WGRAD_LANE', '1') != '0'     # A/B switch: weight gradients on a side stream
+
+
+class _Lane:
+    """Weight / bias-gradient kernels are off the data-flow chain of the backward pass (activation backward -> data
+    gradient -> next layer): they run on a side HIP stream beside it and are joined at the end of the Function's
+    backward.  Tensors allocated on the main stream and read there are protected with record_stream; workspaces are
+    allocated under the side stream."""
+    _streams = {}
+
+    def __init__(self, dev, enabled=True):
+        self.main = torch.cuda.current_stream()
+        self.side = None
+        if enabled and WGRAD_LANE:
+            key = (torch.device(dev).index, 'unet_wgrad')
+            if key not in _Lane._streams:
+                _Lane._streams[key] = torch.cuda.Stream(device=dev)
+            self.side = _Lane._streams[key]
+
+    def run(self, fn, reads=()):
+        if self.side is None:
+            fn()
+            return
+        self.side.wait_stream(self.main)
+        for t in reads:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
 
 ENC_CH = ((4, 8), (8, 16), (16, 32), (32, 64))      # down1..4 (unet.py:100-103)
 DEC_CH = ((64, 32), (32, 16), (16, 8), (8, 4))      # up1..4   (unet.py:178-181)
@@ -126,7 +162,7 @@ def _dastride(t):
     return t, t.stride(0)
 
 
-def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=True, dx_bf=False):
+def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=True, dx_bf=False, lane=None):
     """Backward of DoubleConv.  da: gradient w.r.t. the activated output view (may be a channel slice of
     a wider buffer), dp: gradient w.r.t. its 2x2 max-pooled version.  Returns the gradient w.r.t. the
     (activated) channel-concatenated input, shape (n, C0+C1, H, W), or None."""
@@ -148,14 +184,19 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
                (L.BF_IN0 * _is_bf(y)) | (L.BF_IN1 * _is_bf(da_t)) | (L.BF_DP * _is_bf(dp_t)) | (L.BF_OUT * _is_bf(dy)), st)
         return dy
 
+    lane = lane or _Lane(dev, False)
+
     def wgrad(dy, views, wkey):
         Ci = sum(v.C for v in views)
         dW = grads.buf(wkey, (Co, Ci, 3, 3))
-        ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * HW), device=dev, dtype=torch.float32)
         a1 = views[1].args() if len(views) > 1 else _NOVIEW
         dt = (L.BF_DY * _is_bf(dy)) | (L.BF_IN0 * views[0].bf) | (L.BF_IN1 * (views[1].bf if len(views) > 1 else 0)) | math
-        L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * HW, Co, *views[0].args(), *a1, gs, n, H, W, L.ptr(dW),
-               L.ptr(ws), dt, st)
+
+        def fn():
+            ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * HW), device=dev, dtype=torch.float32)
+            L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * HW, Co, *views[0].args(), *a1, gs, n, H, W, L.ptr(dW),
+                   L.ptr(ws), dt, L.stream())
+        lane.run(fn, reads=[dy, dW] + [t for v in views for t in (v.t, v.sc, v.sh)])
 
     def dgrad(dy, Wt, out_bf):
         Ci = Wt.shape[1]
@@ -211,20 +252,25 @@ def fc_block_fwd(p, pre, x, drop):
     return dict(pre=pre, x=x, h1=h1, d1=d1, h2=h2, drop=drop), h2
 
 
-def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True):
+def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True, lane=None):
     lib = L.load()
     st = L.stream()
     pre, x, h1, d1, h2 = sv['pre'], sv['x'], sv['h1'], sv['d1'], sv['h2']
     dev = x.device
     P = x.shape[0]
+    lane = lane or _Lane(dev, False)
 
     def lin_bwd(dout, inp, wkey, bkey, need_in):
         W = p[wkey]
         Co, Ci = W.shape
         dW = grads.buf(wkey, (Co, Ci))
         db = grads.buf(bkey, (Co,))
-        ws = torch.empty(lib.mo_wgrad_ws_floats(Co, Ci, P), device=dev, dtype=torch.float32)
-        L.call('mo_conv1x1_bwd_weight', L.ptr(dout), Co, P, L.ptr(inp), Ci, 0, 0, 0, 0, L.ptr(dW), L.ptr(db), L.ptr(ws), st)
+
+        def fn():
+            ws = torch.empty(lib.mo_wgrad_ws_floats(Co, Ci, P), device=dev, dtype=torch.float32)
+            L.call('mo_conv1x1_bwd_weight', L.ptr(dout), Co, P, L.ptr(inp), Ci, 0, 0, 0, 0, L.ptr(dW), L.ptr(db), L.ptr(ws),
+                   L.stream())
+        lane.run(fn, reads=[dout, inp, dW, db])
         if not need_in:
             return None
         din = _empty(P, Ci, dev=dev)
@@ -311,16 +357,18 @@ class UnetEncodeFn(torch.autograd.Function):
         outs = ctx.saved_tensors
         fc_sv = dict(ctx.fc_sv, h2=outs[0])
         saved = [dict(sv, y2=outs[1 + k]) if k < 4 else sv for k, sv in enumerate(saved)]
-        dx5a = fc_block_bwd(p, fc_sv, dfeat, grads)
+        lane = _Lane(dev)
+        dx5a = fc_block_bwd(p, fc_sv, dfeat, grads, lane=lane)
         v5 = saved[4]
         dp = double_conv_bwd(p, saved[4], n, gs, grads, dev, da=dx5a.view(n, v5['Co'], v5['H'], v5['W']), dp=None,
-                             dx_bf=bool(saved[4]['views'][0].bf))
+                             dx_bf=bool(saved[4]['views'][0].bf), lane=lane)
         dfm = [dfm1, dfm2, dfm3, dfm4]
         for k in (3, 2, 1, 0):
             need = (k > 0) or ctx.x_needs_grad
             # the gradient w.r.t. a level's pooled input is the dp of the level above: stored as that input is
             dp = double_conv_bwd(p, saved[k], n, gs, grads, dev, da=dfm[k], dp=dp, need_input_grad=need,
-                                 dx_bf=bool(k > 0 and saved[k]['views'][0].bf))
+                                 dx_bf=bool(k > 0 and saved[k]['views'][0].bf), lane=lane)
+        lane.join()
         return (None, dp) + grads.result(state['names'])
 
 
@@ -378,10 +426,14 @@ class UnetDecodeFn(torch.autograd.Function):
         HW = v.H * v.W
         dWo = grads.buf('expansion.outc.conv.weight', Wo.shape)
         dbo = grads.buf('expansion.outc.conv.bias', (Cout,))
-        ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), n * Cout * 2), device=dev,
-                         dtype=torch.float32)
-        L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Cout * HW, Cout, L.ptr(v.t), v.istride, C4, L.ptr(v.sc),
-               L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), L.BF_IN0 * v.bf, st)
+        lane = _Lane(dev)
+
+        def outc_wgrad():
+            ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), n * Cout * 2), device=dev,
+                             dtype=torch.float32)
+            L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Cout * HW, Cout, L.ptr(v.t), v.istride, C4, L.ptr(v.sc),
+                   L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), L.BF_IN0 * v.bf, L.stream())
+        lane.run(outc_wgrad, reads=[dout, v.t, v.sc, v.sh, dWo, dbo])
         da = _empty(n, C4, v.H, v.W, dev=dev, bf=bool(v.bf))
         L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW,
                L.BF_OUT * v.bf, st)
@@ -389,19 +441,24 @@ class UnetDecodeFn(torch.autograd.Function):
         for k in (4, 3, 2, 1):
             up = ctx.ups[k - 1]
             ci, H, vin = up['ci'], up['H'], up['vin']
-            dcat = double_conv_bwd(p, up['dc'], n, gs, grads, dev, da=da, dp=None)     # (n, ci, 2H, 2H)
+            dcat = double_conv_bwd(p, up['dc'], n, gs, grads, dev, da=da, dp=None, lane=lane)     # (n, ci, 2H, 2H)
             C0 = ci // 2
             dfm[4 - k] = dcat[:, :C0]
             du = dcat[:, C0:]
             du_stride = dcat.stride(0)
             Wt = p[f'expansion.up{k}.up.weight']
             dWt = grads.buf(f'expansion.up{k}.up.weight', Wt.shape)
-            wsu = torch.empty(max(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), n * C0 * 2), device=dev,
-                              dtype=torch.float32)
             dbt = grads.buf(f'expansion.up{k}.up.bias', (C0,))
-            L.call('mo_convt2x2_bwd_weight', du.data_ptr(), du_stride, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
-                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(dbt), L.ptr(wsu), st)
+
+            def convt_wgrad(du=du, du_stride=du_stride, C0=C0, vin=vin, ci=ci, H=H, dWt=dWt, dbt=dbt):
+                wsu = torch.empty(max(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), n * C0 * 2), device=dev,
+                                  dtype=torch.float32)
+                L.call('mo_convt2x2_bwd_weight', du.data_ptr(), du_stride, C0, L.ptr(vin.t), vin.istride, ci,
+                       L.ptr(vin.sc), L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(dbt),
+                       L.ptr(wsu), L.stream())
+            lane.run(convt_wgrad, reads=[dcat, vin.t, vin.sc, vin.sh, dWt, dbt])
             da = _empty(n, ci, H, H, dev=dev)
             L.call('mo_convt2x2_bwd_data', du.data_ptr(), du_stride, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
-        dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads)
+        dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads, lane=lane)
+        lane.join()
         return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(state['names'])
