@@ -138,7 +138,9 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device (the raw query: torch.cuda.current_stream() builds a
+    Stream object, ~10 us per call and one call per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def ptr_array(tensors):
@@ -146,6 +148,13 @@ def ptr_array(tensors):
     return arr
 
 
+_fns = {}
+
+
 def call(name, *args):
-    lib = load()
-    check(getattr(lib, name)(*args), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        check(rc, name)

@@ -227,12 +227,18 @@ class gwnet(nn.Module):
             self._statics_dev = key
         return self._statics, self._order[0], self._order[1]
 
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop('_mo_named', None)
+        return super()._apply(fn, *a, **kw)
+
     def body(self, x):
         """graph_wavenet.py:191-254 on a (B, in_dim, N, T) tensor -> (B, out_dim, N, T_final)."""
         if not x.is_cuda:
             raise RuntimeError('gwnet runs on the MI355X HIP path only (no CPU fallback); got a CPU tensor')
         names = self._engine_names()
-        named = dict(self.named_parameters())
+        named = self.__dict__.get('_mo_named')
+        if named is None:                              # (walked once; _apply drops it when .to() replaces the Parameters)
+            named = self.__dict__['_mo_named'] = dict(self.named_parameters())
         params = [named[k] for k in names]
         cfg = GwnetConfig(num_nodes=self.num_nodes, in_dim=self.in_dim, out_dim=self.out_dim,
                           kernel_size=self.kernel_size, blocks=self.blocks, layers=self.layers,

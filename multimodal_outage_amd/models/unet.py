@@ -183,6 +183,20 @@ class Modified_UNET(nn.Module):
     def _names(self, prefixes):
         return [k for k, _ in self.named_parameters() if k.split('.')[0] in prefixes]
 
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop('_mo_plumbing', None)       # .to() / .cuda() may replace the Parameter objects
+        return super()._apply(fn, *a, **kw)
+
+    def _plumbing(self):
+        """(name -> Parameter, encoder-side names, decoder-side names, BatchNorm buffers): walked once, not per step
+        (four traversals of the module tree were ~1 ms of host time per forward)."""
+        c = self.__dict__.get('_mo_plumbing')
+        if c is None:
+            c = (dict(self.named_parameters()), self._names(('contraction', 'encoder')),
+                 self._names(('decoder', 'expansion')), self._bufs())
+            self.__dict__['_mo_plumbing'] = c
+        return c
+
     def _bufs(self):
         out = {}
         for name, m in self.named_modules():
@@ -197,16 +211,14 @@ class Modified_UNET(nn.Module):
         B, NC, H, Cin, S, _ = input.shape
         assert NC == self.n_counties and H == self.horizon and S == self.image_dimension
         n = B * NC * H
-        named = dict(self.named_parameters())
+        named, enc_names, dec_names, bufs = self._plumbing()
         # optional {parameter name: preallocated gradient tensor} of a flat-buffer trainer (FlatTrainer.attach): the
         # engine then writes the UNet-side gradients in place instead of handing new tensors to autograd.  The
         # Graph-WaveNet inside is called once per batch element (unet.py:221): with B > 1 its gradients must accumulate
         # through autograd.
-        state = dict(gsize=H, training=self.training, bufs=self._bufs(),
+        state = dict(gsize=H, training=self.training, bufs=bufs,
                      fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None),
                      act_dtype=getattr(self, 'act_dtype', 'f32'))
-        enc_names = self._names(('contraction', 'encoder'))
-        dec_names = self._names(('decoder', 'expansion'))
         st_e = dict(state, names=enc_names)
         outs = UnetEncodeFn.apply(st_e, input.reshape(n, Cin, S, S).float(), *[named[k] for k in enc_names])
         feat, fms = outs[0], outs[1:]
