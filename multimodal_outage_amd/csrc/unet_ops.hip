@@ -928,38 +928,32 @@ __global__ void unet_act_bwd_param_kernel(const double* __restrict__ k12, long G
   for (long g = 0; g < G; ++g) { db += k12[(g * C + c) * 2]; dg += k12[(g * C + c) * 2 + 1]; }
   dgamma[c] = (float)(dg * M); dbeta[c] = (float)(db * M);
 }
-// final + param in one workgroup (two dependent 5..16 us launches per layer before)
-__global__ __launch_bounds__(1024) void unet_act_bwd_final_param_kernel(const double* __restrict__ part, long G, int C,
-                                                                        int gsize, int HW, int S, double* __restrict__ k12,
-                                                                        float* dgamma, float* dbeta) {
+// final + param in one launch (two dependent 5..16 us launches per layer before): one workgroup per channel, one thread
+// per group (k12 of the group from its partial rows), then the groups folded in a fixed order for dgamma / dbeta
+__global__ __launch_bounds__(256) void unet_act_bwd_final_param_kernel(const double* __restrict__ part, long G, int C,
+                                                                       int gsize, int HW, int S, double* __restrict__ k12,
+                                                                       float* dgamma, float* dbeta) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x;
   const double M = (double)gsize * HW;
-  for (long i = threadIdx.x; i < G * C; i += 1024) {
-    const long g = i / C; const int c = (int)(i - g * C);
+  double dg = 0.0, db = 0.0;
+  for (long g = threadIdx.x; g < G; g += 256) {
     double s1 = 0.0, s2 = 0.0;
     for (int j = 0; j < gsize * S; ++j) {
-      const double* p = part + ((g * gsize * S + j) * C + c) * 2;
-      s1 += p[0]; s2 += p[1];
+      const double2 p = *reinterpret_cast<const double2*>(part + ((g * gsize * S + j) * C + c) * 2);
+      s1 += p.x; s2 += p.y;
     }
-    k12[i * 2] = s1 / M;
-    k12[i * 2 + 1] = s2 / M;
+    const double k1 = s1 / M, k2 = s2 / M;
+    k12[(g * C + c) * 2] = k1; k12[(g * C + c) * 2 + 1] = k2;
+    db += k1; dg += k2;
   }
-  __threadfence();
+  red[0][threadIdx.x] = dg; red[1][threadIdx.x] = db;
   __syncthreads();
-  // per channel: 4 threads x G/4 groups each, folded in a fixed order
-  const int c = threadIdx.x >> 2, sub = threadIdx.x & 3;
-  __shared__ double red[1024][2];
-  double dg = 0.0, db = 0.0;
-  if (c < C) {
-    const volatile double* kv = k12;                               // (written by this workgroup above)
-    for (long g = sub; g < G; g += 4) { db += kv[(g * C + c) * 2]; dg += kv[(g * C + c) * 2 + 1]; }
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
+    __syncthreads();
   }
-  red[threadIdx.x][0] = dg; red[threadIdx.x][1] = db;
-  __syncthreads();
-  if (c < C && sub == 0) {
-    const int t = threadIdx.x;
-    dgamma[c] = (float)(((red[t][0] + red[t + 1][0]) + (red[t + 2][0] + red[t + 3][0])) * M);
-    dbeta[c] = (float)(((red[t][1] + red[t + 1][1]) + (red[t + 2][1] + red[t + 3][1])) * M);
-  }
+  if (threadIdx.x == 0) { dgamma[c] = (float)(red[0][0] * M); dbeta[c] = (float)(red[1][0] * M); }
 }
 __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -1017,8 +1011,8 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img, S), dim3(nthr), 0, st, y, istride,
                      C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part, fl);
   const long G = n_img / gsize;
-  if (C <= 256 && G * C <= 65536) {
-    hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(1), dim3(1024), 0, st, part, G, C, gsize, HW, S, k12, dgamma, dbeta);
+  if (C <= 65535) {
+    hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(C), dim3(256), 0, st, part, G, C, gsize, HW, S, k12, dgamma, dbeta);
   } else {
     hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, S, k12);
     hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
