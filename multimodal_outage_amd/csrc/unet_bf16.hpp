@@ -66,8 +66,11 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   __shared__ float red[4][32 * NB];
   const UdConvArgs& a = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
+  // a workgroup owns a band of TH image rows and walks its tiles_x tiles left to right (then the next image): the
+  // cache lines a tile shares with its neighbour (the halo quad of a 128-byte bf16 row segment is a whole extra line on
+  // either side) are then re-read by the same CU a moment later instead of by another XCD from HBM
   const int tiles_x = a.Wd / TW;
-  const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
+  const int y0 = blockIdx.x * TH;
   const int Ci = a.C0 + a.C1;
   const int es0 = a.bf0 ? 2 : 4, es1 = a.bf1 ? 2 : 4, eso = a.bfo ? 2 : 4;
   const int HW = a.H * a.Wd;
@@ -114,32 +117,36 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   // staging tasks of this thread: the same for every image and band.  toff: byte offset inside the image of
   // (first channel of the quad, row y0 + r - 1, column x); trow: that row, or far outside for lanes without a task /
   // columns outside the image; tdst: LDS element of (row r, column, channel quad)
-  int toff[NTS], trow[NTS], tdst[NTS];
+  int toff[NTS], trow[NTS], tcol[NTS], tdst[NTS];
 #pragma unroll
   for (int t = 0; t < NTS; ++t) {
     const int idx = tid + t * 256;
     const int cq = idx / (NR * QH), r2 = idx - cq * (NR * QH), r = r2 / QH, q = r2 - r * QH;
-    const int x = x0 + 4 * q - 4;
-    toff[t] = (cq * 4 * a.H + y0 + r - 1) * a.Wd + x;     // in ELEMENTS (the two views may differ in width)
-    trow[t] = (idx < NTASK && (unsigned)x < (unsigned)a.Wd) ? y0 + r - 1 : -(1 << 24);
+    tcol[t] = 4 * q - 4;                                  // column relative to the tile
+    toff[t] = (cq * 4 * a.H + y0 + r - 1) * a.Wd + tcol[t];   // in ELEMENTS (the two views may differ in width), tile 0
+    trow[t] = y0 + r - 1;
     tdst[t] = (idx < NTASK) ? (r * LDT + 4 * q) * CP + cq * 4 : -1;
   }
   // output: lane (co = lp + 16 nb, pixels 4 lg .. 4 lg + 3 of a block)
   unsigned vout[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
-    vout[nb] = (nb * 16 + lp < a.Co) ? (unsigned)((((nb * 16 + lp) * a.H + y0 + wave * WR) * a.Wd + x0 + 4 * lg) * eso) : UB_OOB;
+    vout[nb] = (nb * 16 + lp < a.Co) ? (unsigned)((((nb * 16 + lp) * a.H + y0 + wave * WR) * a.Wd + 4 * lg) * eso) : UB_OOB;
 
-  // ---- the workgroup's stages: (image, band of RB rows) in order.  Software pipeline: the global loads of stage k+1 are
+  // ---- the workgroup's stages: (image, tile of the row band, band of RB rows) in order.  Software pipeline: the global loads of stage k+1 are
   // issued in front of the matrix phase of stage k and wait in registers, so their latency is covered by it:
   //   barrier | convert + write LDS (stage k) | barrier | issue loads (k+1) | matrix phase (k) | ...
   constexpr int NBI = TH / RB;                            // bands per image
   const long img0 = (long)blockIdx.y * A.img_per_wg;
   const long img1 = min(img0 + (long)A.img_per_wg, (long)A.n_img);
-  const int nstage = (int)(img1 - img0) * NBI;
+  const int SPI = NBI * tiles_x;                          // stages per image
+  const int nstage = (int)(img1 - img0) * SPI;
   ub_u4 raw[NT][4];
+  auto inside = [&](const int tl, const int tx, const int b) {
+    return tdst[tl] >= 0 && (unsigned)(trow[tl] + b * RB) < (unsigned)a.H && (unsigned)(tcol[tl] + tx * TW) < (unsigned)a.Wd;
+  };
 
-  auto load_view = [&](auto bfc, const int sec, const long img, const int b) {
+  auto load_view = [&](auto bfc, const int sec, const long img, const int tx, const int b) {
     constexpr bool BF = decltype(bfc)::value;
     constexpr int es = BF ? 2 : 4;
     const __amdgpu_buffer_rsrc_t rs = sec ? ub_rsrc(reinterpret_cast<const char*>(a.in1) + img * a.is1 * es, (long)a.C1 * HW * es)
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     const int pb = HW * es;                               // channels past the view's count fall out of the descriptor's range
 #pragma unroll
     for (int tl = 0; tl < NTS; ++tl) {
-      const unsigned off = (unsigned)((toff[tl] + b * RB * a.Wd) * es);
+      const unsigned off = inside(tl, tx, b) ? (unsigned)((toff[tl] + tx * TW + b * RB * a.Wd) * es) : UB_OOB;   // (nothing is fetched for the padding)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ub_u4& d = raw[sec * NTS + tl][j];
@@ -157,13 +164,13 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     }
   };
   auto issue_loads = [&](const int k) {
-    const long img = img0 + k / NBI;
-    const int b = k % NBI;
-    if (a.bf0) load_view(UbBool<true>{}, 0, img, b); else load_view(UbBool<false>{}, 0, img, b);
-    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, 1, img, b); else load_view(UbBool<false>{}, 1, img, b); }
+    const long img = img0 + k / SPI;
+    const int tx = (k / NBI) % tiles_x, b = k % NBI;
+    if (a.bf0) load_view(UbBool<true>{}, 0, img, tx, b); else load_view(UbBool<false>{}, 0, img, tx, b);
+    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, 1, img, tx, b); else load_view(UbBool<false>{}, 1, img, tx, b); }
   };
   // activation (folded BatchNorm affine, ReLU), rounding to bf16, transposition to channels-last, LDS
-  auto commit_view = [&](auto bfc, const int sec, const int b) {
+  auto commit_view = [&](auto bfc, const int sec, const int tx, const int b) {
     constexpr bool BF = decltype(bfc)::value;
     const float flo = (sec ? a.relu1 : a.relu0) ? 0.f : -__builtin_inff();
 #pragma unroll
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
       const float scj[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shj[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
       // zero padding comes AFTER the activation: rows / columns outside the image are zero, not relu(shift); what the
       // loads brought from there (a neighbouring row or plane, or the range check's zero) is multiplied away
-      const float keep = ((unsigned)(trow[tl] + b * RB) < (unsigned)a.H) ? 1.f : 0.f;
+      const float keep = inside(tl, tx, b) ? 1.f : 0.f;
       float4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   float s1[NB], s2[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
-  auto matrix_phase = [&](auto bfoc, const long img, const int b) {
+  auto matrix_phase = [&](auto bfoc, const long img, const int tx, const int b) {
     constexpr bool BFO = decltype(bfoc)::value;
     constexpr int eo = BFO ? 2 : 4;
     const __amdgpu_buffer_rsrc_t ro = ub_rsrc(reinterpret_cast<char*>(a.out) + img * a.os * eo, (long)a.Co * HW * eo);
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     for (int rr = 0; rr < WR; ++rr) {
       unsigned vo[NB];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) vo[nb] = vout[nb] + (unsigned)((b * RB + rr) * a.Wd * eo);   // (UB_OOB stays out of range)
+      for (int nb = 0; nb < NB; ++nb) vo[nb] = vout[nb] + (unsigned)(((b * RB + rr) * a.Wd + tx * TW) * eo);   // (UB_OOB stays out of range)
 #pragma unroll
       for (int cb = 0; cb < TW / 16; ++cb) {
         ub_f4 acc[NB];
@@ -272,17 +279,17 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   if (nstage > 0) { load_affine(img0); issue_loads(0); }
 #pragma unroll 1
   for (int k = 0; k < nstage; ++k) {
-    const long img = img0 + k / NBI;
-    const int b = k % NBI;
+    const long img = img0 + k / SPI;
+    const int tx = (k / NBI) % tiles_x, b = k % NBI;
     __syncthreads();                                      // stage k-1's matrix phase is done with the tile; aff is in place
-    if (a.bf0) commit_view(UbBool<true>{}, 0, b); else commit_view(UbBool<false>{}, 0, b);
-    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, 1, b); else commit_view(UbBool<false>{}, 1, b); }
+    if (a.bf0) commit_view(UbBool<true>{}, 0, tx, b); else commit_view(UbBool<false>{}, 0, tx, b);
+    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, 1, tx, b); else commit_view(UbBool<false>{}, 1, tx, b); }
     __syncthreads();
     if (k + 1 < nstage) {
       issue_loads(k + 1);
-      if (b == NBI - 1 && (img + 1) % a.gsize == 0) load_affine(img + 1);     // (every reader of aff is past the barrier)
+      if ((k + 1) % SPI == 0 && (img + 1) % a.gsize == 0) load_affine(img + 1);     // (every reader of aff is past the barrier)
     }
-    if (a.bfo) matrix_phase(UbBool<true>{}, img, b); else matrix_phase(UbBool<false>{}, img, b);
+    if (a.bfo) matrix_phase(UbBool<true>{}, img, tx, b); else matrix_phase(UbBool<false>{}, img, tx, b);
     if (b == NBI - 1) {
       if (a.stats) {                                      // per-tile BatchNorm statistics from the accumulators
 #pragma unroll
@@ -294,8 +301,8 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
         }
         __syncthreads();
         if (tid < 32 * NB && (tid >> 1) < a.Co) {
-          const long ntile = gridDim.x;
-          a.stats[((img * ntile + blockIdx.x) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
+          const long ntile = (long)gridDim.x * tiles_x;
+          a.stats[((img * ntile + (long)blockIdx.x * tiles_x + tx) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
               (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         }
       }
@@ -340,21 +347,21 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
   float* fold = reinterpret_cast<float*>(smem);            // (after the last stage)
   __shared__ float aff[2][CI];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
-  const int tiles_x = a.Wd / TW;
-  const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
+  const int tiles_x = a.Wd / TW;                         // (a workgroup walks the tiles of its row band left to right,
+  const int y0 = blockIdx.x * TH;                         //  as ub_conv3x3_kernel does)
   const int Ci = a.C0 + a.C1;
   const int HW = a.H * a.Wd;
 
   // staging pattern of one channel pair (the same for every pair, view, image and stage)
-  int toff[NP], tdst[NP], trow[NP];
+  int toff[NP], tdst[NP], trow[NP], tcol[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int idx = tid + p * 256;
     const int cl = idx / (NR * QH), r2 = idx - cl * (NR * QH), r = r2 / QH, q = r2 - r * QH;
-    const int x = x0 + 4 * q - 4;
-    toff[p] = (cl * a.H + y0 + r - 1) * a.Wd + x;
+    tcol[p] = 4 * q - 4;
+    toff[p] = (cl * a.H + y0 + r - 1) * a.Wd + tcol[p];
     tdst[p] = (idx < TPP) ? cl * PS + r * LDW + 4 * q + 4 : -1;
-    trow[p] = (idx < TPP && (unsigned)x < (unsigned)a.Wd) ? y0 + r - 1 : -(1 << 24);
+    trow[p] = y0 + r - 1;
   }
   // A fragments: LDS byte address of this lane's 8 pixels (kx = 1) in the first row / half of the wave
   int abase[NJ];
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
   unsigned dyo[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
-    dyo[nb] = (nb * 16 + lp < a.Co) ? (unsigned)((((nb * 16 + lp) * a.H + y0 + wave * (RB / 4)) * a.Wd + x0 + 8 * lg) * 2) : UB_OOB;
+    dyo[nb] = (nb * 16 + lp < a.Co) ? (unsigned)((((nb * 16 + lp) * a.H + y0 + wave * (RB / 4)) * a.Wd + 8 * lg) * 2) : UB_OOB;
 
   ub_f4 acc[NJ][3][NB];
 #pragma unroll
@@ -379,11 +386,15 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
 
   const long img0 = (long)blockIdx.y * a.img_per_wg;
   const long img1 = min(img0 + (long)a.img_per_wg, a.n_img);
-  const int nstage = (int)(img1 - img0) * NBI;
-  ub_u4 raw[NV * NTV];                                    // (bf16 views use two dwords of each)
+  const int SPI = NBI * tiles_x;                          // stages per image
+  const int nstage = (int)(img1 - img0) * SPI;
+  ub_u4 raw[NV * NTV];
+  auto inside = [&](const int p, const int tx, const int b) {
+    return tdst[p] >= 0 && (unsigned)(trow[p] + b * RB) < (unsigned)a.H && (unsigned)(tcol[p] + tx * TW) < (unsigned)a.Wd;
+  };                                    // (bf16 views use two dwords of each)
   ub_u4 dyr[KS][NB];
 
-  auto load_view = [&](auto bfc, const int sec, const long img, const int b) {
+  auto load_view = [&](auto bfc, const int sec, const long img, const int tx, const int b) {
     constexpr bool BF = decltype(bfc)::value;
     constexpr int es = BF ? 2 : 4;
     const __amdgpu_buffer_rsrc_t rs = sec ? ub_rsrc(reinterpret_cast<const char*>(a.in1) + img * a.is1 * es, (long)a.C1 * HW * es)
@@ -392,25 +403,25 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
     for (int cp = 0; cp < NCP; ++cp)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const unsigned off = (unsigned)((toff[p] + cp * 2 * HW + b * RB * a.Wd) * es);
+        const unsigned off = inside(p, tx, b) ? (unsigned)((toff[p] + cp * 2 * HW + tx * TW + b * RB * a.Wd) * es) : UB_OOB;
         ub_u4& d = raw[sec * NTV + cp * NP + p];
         if (BF) { const ub_u2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0); d[0] = u[0]; d[1] = u[1]; }
         else d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
       }
   };
   auto issue_loads = [&](const int k) {
-    const long img = img0 + k / NBI;
-    const int b = k % NBI;
-    if (a.bf0) load_view(UbBool<true>{}, 0, img, b); else load_view(UbBool<false>{}, 0, img, b);
-    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, 1, img, b); else load_view(UbBool<false>{}, 1, img, b); }
+    const long img = img0 + k / SPI;
+    const int tx = (k / NBI) % tiles_x, b = k % NBI;
+    if (a.bf0) load_view(UbBool<true>{}, 0, img, tx, b); else load_view(UbBool<false>{}, 0, img, tx, b);
+    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, 1, img, tx, b); else load_view(UbBool<false>{}, 1, img, tx, b); }
     const __amdgpu_buffer_rsrc_t rd = ub_rsrc(reinterpret_cast<const char*>(a.dy) + img * a.dys * 2, (long)a.Co * HW * 2);
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        dyr[s][nb] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)(dyo[nb] + (unsigned)(((b * RB + (s >> 1)) * a.Wd + 32 * (s & 1)) * 2)), 0, 0);
+        dyr[s][nb] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)(dyo[nb] + (unsigned)(((b * RB + (s >> 1)) * a.Wd + tx * TW + 32 * (s & 1)) * 2)), 0, 0);
   };
-  auto commit_view = [&](auto bfc, const int sec, const int b) {
+  auto commit_view = [&](auto bfc, const int sec, const int tx, const int b) {
     constexpr bool BF = decltype(bfc)::value;
     const float flo = (sec ? a.relu1 : a.relu0) ? 0.f : -__builtin_inff();
 #pragma unroll
@@ -420,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
         const int cbase = sec * CS + cp * 2;
         const int dst = tdst[p] + cbase * PS;
         const int ch = cbase + ((tdst[p] >= PS) ? 1 : 0);
-        const float keep = ((unsigned)(trow[p] + b * RB) < (unsigned)a.H) ? 1.f : 0.f;
+        const float keep = inside(p, tx, b) ? 1.f : 0.f;
         const float s_ = aff[0][ch] * keep, t_ = aff[1][ch] * keep;
         const ub_u4& d = raw[sec * NTV + cp * NP + p];
         const unsigned ux = d[0], uy = d[1];
@@ -452,11 +463,11 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
   if (nstage > 0) { load_affine(img0); issue_loads(0); }
 #pragma unroll 1
   for (int k = 0; k < nstage; ++k) {
-    const long img = img0 + k / NBI;
-    const int b = k % NBI;
+    const long img = img0 + k / SPI;
+    const int tx = (k / NBI) % tiles_x, b = k % NBI;
     __syncthreads();                                      // stage k-1's matrix phase is done with the tile; aff is in place
-    if (a.bf0) commit_view(UbBool<true>{}, 0, b); else commit_view(UbBool<false>{}, 0, b);
-    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, 1, b); else commit_view(UbBool<false>{}, 1, b); }
+    if (a.bf0) commit_view(UbBool<true>{}, 0, tx, b); else commit_view(UbBool<false>{}, 0, tx, b);
+    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, 1, tx, b); else commit_view(UbBool<false>{}, 1, tx, b); }
     ub_u4 dyc[KS][NB];                                    // this stage's dy fragments (the registers are refilled below)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
     __syncthreads();
     if (k + 1 < nstage) {
       issue_loads(k + 1);
-      if (b == NBI - 1 && (img + 1) % a.gsize == 0) load_affine(img + 1);
+      if ((k + 1) % SPI == 0 && (img + 1) % a.gsize == 0) load_affine(img + 1);
     }
     const char* lds = reinterpret_cast<const char*>(xs);
 #pragma unroll

@@ -222,12 +222,12 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
     a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
     A.flip = (dtypes & MO_W_FLIP) != 0; A.n_img = (int)n_img;
-    const long tiles = (long)(Wd / UB_TW) * (H / UB_TH);
-    long ipw = (tiles * n_img) / 1024;                    // images per workgroup (weights / staging pattern are set up once per workgroup)
+    const long bands = H / UB_TH;                         // a workgroup = one band of 16 rows x a range of images
+    long ipw = (bands * n_img) / 1024;                    // (weights / staging pattern are set up once per workgroup)
     if (ipw < 1) ipw = 1;
     while ((n_img + ipw - 1) / ipw >= 65536) ++ipw;
     A.img_per_wg = (int)ipw;
-    dim3 grid((unsigned)tiles, (unsigned)((n_img + ipw - 1) / ipw));
+    dim3 grid((unsigned)bands, (unsigned)((n_img + ipw - 1) / ipw));
     hipStream_t st = ST(stream);
     if (Ci <= 4) ub_launch<4, 16>(A, Co, false, grid, st);
     else if (Ci <= 8) ub_launch<8, 16>(A, Co, C1 > 0, grid, st);
@@ -326,7 +326,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
   if ((dtypes & MO_BF_MATH) && (dtypes & MO_BF_DY) && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 7) == 0 &&
       Co <= 16 && (C1 == 0 || (C0 == C1 && (C0 == 4 || C0 == 8 || C0 == 16))) && mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) {
     // bf16 matrix pipe (unet_bf16.hpp): one slab row per (tile position, image range)
-    const long tiles = (long)(Wd / UB_TW) * (H / UB_TH);
+    const long tiles = H / UB_TH;                         // slab rows per image range: one per band of 16 image rows
     const long max_rows = ((long)Co * Ci * 9 <= UW_THIN_ROW) ? UW_THIN_SLABS : UD_MAX_SLABS;
     long ipw = (n_img * tiles + 1023) / 1024;
     if (ipw * 1 < (n_img * tiles + max_rows - 1) / max_rows) ipw = (n_img * tiles + max_rows - 1) / max_rows;
@@ -866,6 +866,43 @@ __device__ __forceinline__ void unet_dz4(const float* __restrict__ ybase, long y
 #pragma unroll
   for (int i = 0; i < 4; ++i) dz[i] = (a[i] > 0.f) ? d[i] : 0.f;
 }
+template <bool YB, bool DAB, bool DPB>
+__device__ __forceinline__ void unet_dz4_t(const float* __restrict__ ybase, long yoff, int W, int yy, int q, float s, float t,
+                                         const float* __restrict__ da_base, long daoff, const float* __restrict__ dp_base,
+                                         long dpoff, float4& yv, float (&dz)[4]) {
+  yv = ua_ld4(ybase, yoff + (long)yy * W + 4 * q, YB);
+  const float a[4] = {yv.x * s + t, yv.y * s + t, yv.z * s + t, yv.w * s + t};
+  float d[4] = {0.f, 0.f, 0.f, 0.f};
+  if (da_base) {
+    const float4 v = ua_ld4(da_base, daoff + (long)yy * W + 4 * q, DAB);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  if (dp_base) {
+    const float4 ov = ua_ld4(ybase, yoff + (long)(yy ^ 1) * W + 4 * q, YB);
+    const float o[4] = {ov.x * s + t, ov.y * s + t, ov.z * s + t, ov.w * s + t};
+    float2 g;
+    const long gi = dpoff + (long)(yy >> 1) * (W >> 1) + 2 * q;
+    if (DPB) { const unsigned u = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(dp_base) + gi); g = make_float2(ua_lo(u), ua_hi(u)); }
+    else g = *reinterpret_cast<const float2*>(dp_base + gi);
+    const bool top = (yy & 1) == 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      // window values in scan order: top-left, top-right, bottom-left, bottom-right
+      const float v0 = top ? a[2 * w] : o[2 * w], v1 = top ? a[2 * w + 1] : o[2 * w + 1];
+      const float v2 = top ? o[2 * w] : a[2 * w], v3 = top ? o[2 * w + 1] : a[2 * w + 1];
+      int am = 0; float mx = v0;
+      if (v1 > mx) { mx = v1; am = 1; }
+      if (v2 > mx) { mx = v2; am = 2; }
+      if (v3 > mx) { mx = v3; am = 3; }
+      const int me0 = top ? 0 : 2;
+      const float gw = w ? g.y : g.x;
+      if (am == me0) d[2 * w] += gw;
+      if (am == me0 + 1) d[2 * w + 1] += gw;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dz[i] = (a[i] > 0.f) ? d[i] : 0.f;
+}
 __global__ void unet_act_bwd_partial_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                             const float* __restrict__ sc, const float* __restrict__ sh,
@@ -985,6 +1022,86 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   ua_st4(dy, img * dystride + ((long)c * H + yy) * W + 4 * q, o, f.dy);
 }
 #define UA_MAX_SLICES 16
+
+// Two quads per thread, storage types as template parameters (straight-line code: both quads' loads are in flight before
+// the first use).  The one-quad kernels above measured 2.2 .. 2.6 TB/s of their own bytes -- 8 bytes per lane and load.
+template <bool YB, bool DAB, bool DPB>
+__global__ __launch_bounds__(256) void unet_act_bwd_partial2_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
+                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                             const float* __restrict__ sc, const float* __restrict__ sh,
+                                             const float* __restrict__ da, long dastride, const float* __restrict__ dp,
+                                             long dpstride, double* __restrict__ part) {
+  __shared__ double sm[2][256];
+  const int c = blockIdx.x; const long img = blockIdx.y;
+  const long g = img / gsize;
+  const float s = sc[g * C + c], t = sh[g * C + c], mu = mean[g * C + c], rs = rstd[g * C + c];
+  const long yoff = img * istride + (long)c * H * W, daoff = img * dastride + (long)c * H * W;
+  const long dpoff = img * dpstride + (long)c * (H / 2) * (W / 2);
+  const int Q2 = W >> 3;                                           // quad pairs per row
+  double s1 = 0.0, s2 = 0.0;
+  const int per = (H * Q2 + gridDim.z - 1) / gridDim.z;
+  const int i_end = min(H * Q2, (int)(blockIdx.z + 1) * per);
+  for (int i = blockIdx.z * per + threadIdx.x; i < i_end; i += blockDim.x) {
+    const int yy = i / Q2, q = 2 * (i - yy * Q2);
+    float4 yv0, yv1; float d0[4], d1[4];
+    unet_dz4_t<YB, DAB, DPB>(y, yoff, W, yy, q, s, t, da, daoff, dp, dpoff, yv0, d0);
+    unet_dz4_t<YB, DAB, DPB>(y, yoff, W, yy, q + 1, s, t, da, daoff, dp, dpoff, yv1, d1);
+    const float xa[4] = {(yv0.x - mu) * rs, (yv0.y - mu) * rs, (yv0.z - mu) * rs, (yv0.w - mu) * rs};
+    const float xb[4] = {(yv1.x - mu) * rs, (yv1.y - mu) * rs, (yv1.z - mu) * rs, (yv1.w - mu) * rs};
+    s1 += (double)((d0[0] + d0[1]) + (d0[2] + d0[3])) + (double)((d1[0] + d1[1]) + (d1[2] + d1[3]));
+    s2 += ((double)d0[0] * xa[0] + (double)d0[1] * xa[1] + (double)d0[2] * xa[2] + (double)d0[3] * xa[3]) +
+          ((double)d1[0] * xb[0] + (double)d1[1] * xb[1] + (double)d1[2] * xb[2] + (double)d1[3] * xb[3]);
+  }
+  sm[0][threadIdx.x] = s1; sm[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int k = blockDim.x / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) { sm[0][threadIdx.x] += sm[0][threadIdx.x + k]; sm[1][threadIdx.x] += sm[1][threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long row = img * gridDim.z + blockIdx.z;
+    part[(row * C + c) * 2] = sm[0][0]; part[(row * C + c) * 2 + 1] = sm[1][0];
+  }
+}
+template <bool YB, bool DAB, bool DPB, bool DYB>
+__global__ __launch_bounds__(256) void unet_act_bwd_apply2_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
+                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                           const float* __restrict__ rstd, const float* __restrict__ sc,
+                                           const float* __restrict__ sh, const float* __restrict__ da, long dastride,
+                                           const float* __restrict__ dp, long dpstride, const double* __restrict__ k12,
+                                           float* __restrict__ dy, long dystride, long total8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int Q2 = W >> 3;
+  const int q = 2 * (int)(i % Q2); long r = i / Q2;
+  const int yy = (int)(r % H); r /= H;
+  const int c = (int)(r % C); const long img = r / C;
+  const long g = img / gsize;
+  const float s = sc[g * C + c], t = sh[g * C + c], mu = mean[g * C + c], rs = rstd[g * C + c];
+  const long yoff = img * istride + (long)c * H * W, daoff = img * dastride + (long)c * H * W;
+  const long dpoff = img * dpstride + (long)c * (H / 2) * (W / 2);
+  float4 yv0, yv1; float d0[4], d1[4];
+  unet_dz4_t<YB, DAB, DPB>(y, yoff, W, yy, q, s, t, da, daoff, dp, dpoff, yv0, d0);
+  unet_dz4_t<YB, DAB, DPB>(y, yoff, W, yy, q + 1, s, t, da, daoff, dp, dpoff, yv1, d1);
+  const double k1 = k12[(g * C + c) * 2], k2 = k12[(g * C + c) * 2 + 1];
+  const float gr = gamma[c] * rs;
+  float4 o0, o1;
+  o0.x = gr * (float)((double)d0[0] - k1 - (double)((yv0.x - mu) * rs) * k2);
+  o0.y = gr * (float)((double)d0[1] - k1 - (double)((yv0.y - mu) * rs) * k2);
+  o0.z = gr * (float)((double)d0[2] - k1 - (double)((yv0.z - mu) * rs) * k2);
+  o0.w = gr * (float)((double)d0[3] - k1 - (double)((yv0.w - mu) * rs) * k2);
+  o1.x = gr * (float)((double)d1[0] - k1 - (double)((yv1.x - mu) * rs) * k2);
+  o1.y = gr * (float)((double)d1[1] - k1 - (double)((yv1.y - mu) * rs) * k2);
+  o1.z = gr * (float)((double)d1[2] - k1 - (double)((yv1.z - mu) * rs) * k2);
+  o1.w = gr * (float)((double)d1[3] - k1 - (double)((yv1.w - mu) * rs) * k2);
+  const long o = img * dystride + ((long)c * H + yy) * W + 4 * q;
+  if (DYB) {
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(dy) + o) =
+        make_uint4(ua_pack2(o0.x, o0.y), ua_pack2(o0.z, o0.w), ua_pack2(o1.x, o1.y), ua_pack2(o1.z, o1.w));
+  } else {
+    *reinterpret_cast<float4*>(dy + o) = o0; *reinterpret_cast<float4*>(dy + o + 4) = o1;
+  }
+}
 extern "C" long mo_unet_act_bwd_ws_floats(long n_img, int C) { return n_img * C * (4 * UA_MAX_SLICES + 4) + 64; }   // double partials (<= 16 slices per plane) + double k12
 extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int Wd, int gsize,
                                const float* gamma, const float* mean, const float* rstd, const float* sc,
@@ -1008,8 +1125,19 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
   if (S < 1) S = 1;
   double* part = reinterpret_cast<double*>(ws);
   double* k12 = part + n_img * C * 2 * S;
-  hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img, S), dim3(nthr), 0, st, y, istride,
-                     C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part, fl);
+  // two quads per thread with the storage types compiled in (rows of whole quad pairs, 32-byte aligned dy rows)
+  const bool two = (Wd % 8) == 0 && HW >= 1024 && (!fl.dy || ((((uintptr_t)dy) & 15) == 0 && (dystride & 7) == 0));
+#define UA_DISPATCH3(K, ...) do { \
+    if (fl.y) { if (fl.da) { if (fl.dp) K(true, true, true, __VA_ARGS__); else K(true, true, false, __VA_ARGS__); } \
+                else { if (fl.dp) K(true, false, true, __VA_ARGS__); else K(true, false, false, __VA_ARGS__); } } \
+    else { if (fl.da) { if (fl.dp) K(false, true, true, __VA_ARGS__); else K(false, true, false, __VA_ARGS__); } \
+           else { if (fl.dp) K(false, false, true, __VA_ARGS__); else K(false, false, false, __VA_ARGS__); } } } while (0)
+#define UA_PARTIAL2(YB, DAB, DPB, dummy) hipLaunchKernelGGL((unet_act_bwd_partial2_kernel<YB, DAB, DPB>), dim3(C, (unsigned)n_img, S), \
+    dim3(256), 0, st, y, istride, C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part)
+  if (two) UA_DISPATCH3(UA_PARTIAL2, 0);
+  else
+    hipLaunchKernelGGL(unet_act_bwd_partial_kernel, dim3(C, (unsigned)n_img, S), dim3(nthr), 0, st, y, istride,
+                       C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part, fl);
   const long G = n_img / gsize;
   if (C <= 65535) {
     hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(C), dim3(256), 0, st, part, G, C, gsize, HW, S, k12, dgamma, dbeta);
@@ -1018,8 +1146,15 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
     hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
   }
   const long total4 = n_img * C * (HW / 4);
-  hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total4, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
-                     gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4, fl);
+#define UA_APPLY2(YB, DAB, DPB, DYB) hipLaunchKernelGGL((unet_act_bwd_apply2_kernel<YB, DAB, DPB, DYB>), dim3(mo_cdiv(total4 / 2, 256)), \
+    dim3(256), 0, st, y, istride, C, H, Wd, gsize, gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4 / 2)
+  if (two) { if (fl.dy) UA_DISPATCH3(UA_APPLY2, true); else UA_DISPATCH3(UA_APPLY2, false); }
+  else
+    hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total4, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
+                       gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4, fl);
+#undef UA_APPLY2
+#undef UA_PARTIAL2
+#undef UA_DISPATCH3
   return mo_launch_status();
 }
 

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=134)
 ap.add_argument('--only', default='fwd,dgrad,wgrad')
 ap.add_argument('--reps', type=int, default=10)
+ap.add_argument('--layers', default='', help='comma-separated indices into the layer table (default: all)')
 ap.add_argument('--opt', action='append', default=[], help='name=value for mo_unet_set_option')
 a = ap.parse_args()
 lib = L.load()
@@ -42,6 +43,8 @@ def timeit(fn, reps=a.reps):
 LAYERS = [(13, 0, 0, 4, 256), (4, 1, 0, 4, 256), (4, 1, 4, 4, 256), (4, 1, 0, 8, 128), (8, 1, 0, 8, 128), (8, 1, 8, 8, 128),
           (8, 1, 0, 16, 64), (16, 1, 0, 16, 64), (16, 1, 16, 16, 64)]
 print(f'{"layer":26s} {"op":6s} {"fp32 us":>9s} {"bf16-mfma us":>13s} {"MB":>8s} {"TB/s (mfma)":>12s}')
+if a.layers:
+    LAYERS = [LAYERS[int(i)] for i in a.layers.split(',')]
 for C0, bf0, C1, Co, S in LAYERS:
     Ci = C0 + C1
     G = n // gs
