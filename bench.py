@@ -86,6 +86,40 @@ def alg_bytes(dtype):
     return block * N_NODES, step * N_NODES
 
 
+def unet_alg_bytes_fwd(cin, size, act_dtype):
+    """SURVEY 8(d)'s per-op in+out accounting of the UNet conv stack for ONE tile, forward, at the element sizes the
+    engine stores (unet_engine.bf_ok: raw conv outputs and pooled maps of <= 32 channels at >= 64x64 are bf16 in the bf16
+    mode; the network input, the ConvTranspose2d outputs, the second conv output of up1..3, everything below 64x64 and the
+    OutConv result are fp32).  All-fp32 it reproduces the survey's 29.7 MB for a 13x256x256 tile."""
+    from multimodal_outage_amd.unet_engine import bf_ok, ENC_CH, DEC_CH
+    es = lambda co, s: 2 if bf_ok(act_dtype, co, s, s) else 4
+    tot, s = 0, size
+    conv = lambda ci_bytes, co, s_, eo: ci_bytes + co * s_ * s_ * eo
+    # inc
+    e1 = es(4, s)
+    tot += conv(cin * s * s * 4, 4, s, e1) + conv(4 * s * s * e1, 4, s, e1)
+    skips = [(4, s, e1)]
+    c_prev, e_prev = 4, e1
+    for ci, co in ENC_CH:                                  # Down: pool (read + write), DoubleConv
+        s2 = s // 2
+        ep = es(co, s2)
+        tot += ci * s * s * e_prev + ci * s2 * s2 * ep
+        tot += conv(ci * s2 * s2 * ep, co, s2, ep) + conv(co * s2 * s2 * ep, co, s2, ep)
+        s, c_prev, e_prev = s2, co, ep
+        skips.append((co, s, ep))
+    e_in = 4                                               # decoder fc output (fp32)
+    for k, (ci, co) in enumerate(DEC_CH, 1):               # Up: ConvTranspose2d, DoubleConv over [skip, up]
+        s2 = 2 * s
+        tot += ci * s * s * e_in + (ci // 2) * s2 * s2 * 4
+        sk_c, _, sk_e = skips[4 - k]
+        eb = es(co, s2)
+        e2 = eb if k == 4 else 4
+        tot += conv(sk_c * s2 * s2 * sk_e + (ci // 2) * s2 * s2 * 4, co, s2, eb) + conv(co * s2 * s2 * eb, co, s2, e2)
+        s, e_in = s2, e2
+    tot += 4 * s * s * e_in + cin * s * s * 4              # OutConv
+    return float(tot)
+
+
 def unet_pmc_traffic(batch, horizon, cin, size):
     """HBM bytes per step of the whole UNet leg (every kernel: conv stack, FC bottleneck and its Adam, Graph WaveNet, loss)
     from the committed FETCH_SIZE / WRITE_SIZE passes of tools/bench_unet.py (tools/unet_pmc_summary.py); None when the
@@ -93,7 +127,7 @@ def unet_pmc_traffic(batch, horizon, cin, size):
     if (batch, horizon, cin, size) != (1, 2, 13, 256):
         return None
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r02_unet_c3_pmc_traffic.json')))['bytes_per_step']
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r02b_unet_c3_pmc_traffic.json')))['bytes_per_step']
     except Exception:
         return None
 
@@ -243,15 +277,20 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
     # accounting, x3 with backward) over the WHOLE step time (FC bottleneck, the 67-node Graph WaveNet, loss and Adam
     # are inside it); per-kernel durations: profiles/r02_unet_c3_kernel_stats.csv
     scale = (cin * size * size) / (13.0 * 256 * 256) if (cin, size) != (13, 256) else 1.0
-    gbs = 3 * UNET_BYTES_FWD_PER_TILE * scale * tps / world / 1e9
+    alg = unet_alg_bytes_fwd(cin, size, act_dtype)        # at the element sizes stored (the survey's figure is all-fp32)
+    gbs = 3 * alg * tps / world / 1e9
     roof = {"bound": "hbm", "kernel": "UNet conv stack (all kernels of the Modified_UNET step)",
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBPS, 4),
-            "algorithmic_MB_per_tile_fwd": round(UNET_BYTES_FWD_PER_TILE * scale / 1e6, 2),
+            "algorithmic_MB_per_tile_fwd": round(alg / 1e6, 2),
+            "survey_all_fp32_MB_per_tile_fwd": round(unet_alg_bytes_fwd(cin, size, 'f32') / 1e6, 2),
             "vector_TFLOPs": round(3 * UNET_FLOP_FWD_PER_TILE * scale * tps / world / 1e12, 2),
             "traffic": unet_pmc_traffic(batch, horizon, cin, size)}
     return {"metric": "UNet (Modified_UNET) train tiles/sec", "value": round(tps, 1), "unit": "tiles/s", "roofline": roof,
             "ms_per_step": round(dt / steps * 1e3, 2), "tiles_per_step_per_gpu": tiles, "steps": steps, "warmup": warmup,
-            "trace": trace, "dtype": ("bf16 activation storage at >= 64x64, fp32 arithmetic" if act_dtype == 'bf16' else "f32"),
+            "trace": trace,
+            "dtype": ("bf16: activations of <= 32 channels at >= 64x64 stored as bf16; their 3x3 convs, data and weight "
+                      "gradients on the bf16 matrix pipe with fp32 accumulation; everything else fp32"
+                      if act_dtype == 'bf16' else "f32"),
             "data": "synthetic",
             "config": {"workload": f"Modified_UNET fwd+MSE+bwd+Adam on ({batch},67,{horizon},{cin},{size},{size}) tiles",
                        "tile": f"{cin}x{size}x{size}", "counties": 67, "horizon": horizon, "parallelism": f"dp{world}"},
