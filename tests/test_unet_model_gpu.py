@@ -61,9 +61,10 @@ def test_modified_unet_vs_golden(name, B, channels, size, seed):
                                                        ('modified_unet_C3', 1, 13, 256, 410)])
 def test_modified_unet_bf16_storage_mode(name, B, channels, size, seed):
     """BASELINE config 3 names bf16: Modified_UNET.act_dtype = 'bf16' stores the raw conv outputs and their gradients of
-    the large resolutions (>= 64x64) as bf16 in HBM; arithmetic (convs, BatchNorm statistics, weight gradients) stays
-    fp32.  Stated tolerance against the reference goldens (fp32): outputs 5e-2 of the output scale (measured 2.8e-2: ~20
-    bf16-rounded tensors between input and output), loss 1e-2 relative,
+    the large resolutions (>= 64x64) as bf16 in HBM and runs the 3x3 convs of those levels, their data and weight
+    gradients on the bf16 matrix pipe with fp32 accumulation (MO_BF_MATH; BatchNorm statistics, activation backward, FC,
+    ConvTranspose2d, loss and optimizer stay fp32).  Stated tolerance against the reference goldens (fp32): outputs 5e-2
+    of the output scale (measured 3.7e-2: ~20 bf16-rounded tensors between input and output), loss 1e-2 relative,
     parameter gradients against the float64 run of the reference by stage (see below); gradients that are None in the
     reference stay zero."""
     G = golden(name)
