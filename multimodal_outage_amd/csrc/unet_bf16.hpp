@@ -34,6 +34,7 @@ __device__ __forceinline__ unsigned ub_pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((ub_f2){lo, hi}, ub_bf2));
 }
 template <bool B> struct UbBool { static constexpr bool value = B; };
+template <int N> struct UbInt { static constexpr int value = N; };
 
 #define UB_TW 64
 #define UB_TH 16
@@ -141,13 +142,17 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   const long img1 = min(img0 + (long)A.img_per_wg, (long)A.n_img);
   const int SPI = NBI * tiles_x;                          // stages per image
   const int nstage = (int)(img1 - img0) * SPI;
-  ub_u4 raw[NT][4];
+  // prefetch distance in stages (raw[] is a ring of PF register sets).  Two stages ahead was measured for CP <= 8 and
+  // changed nothing (4->4 at 256^2: 61 -> 64 us): the stage is bound by instruction issue, not by the load latency.
+  constexpr int PF = 1;
+  ub_u4 raw[PF][NT][4];
   auto inside = [&](const int tl, const int tx, const int b) {
     return tdst[tl] >= 0 && (unsigned)(trow[tl] + b * RB) < (unsigned)a.H && (unsigned)(tcol[tl] + tx * TW) < (unsigned)a.Wd;
   };
 
-  auto load_view = [&](auto bfc, const int sec, const long img, const int tx, const int b) {
+  auto load_view = [&](auto bfc, auto slotc, const int sec, const long img, const int tx, const int b) {
     constexpr bool BF = decltype(bfc)::value;
+    constexpr int SL = decltype(slotc)::value;
     constexpr int es = BF ? 2 : 4;
     const __amdgpu_buffer_rsrc_t rs = sec ? ub_rsrc(reinterpret_cast<const char*>(a.in1) + img * a.is1 * es, (long)a.C1 * HW * es)
                                           : ub_rsrc(reinterpret_cast<const char*>(a.in0) + img * a.is0 * es, (long)a.C0 * HW * es);
@@ -157,21 +162,22 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
       const unsigned off = inside(tl, tx, b) ? (unsigned)((toff[tl] + tx * TW + b * RB * a.Wd) * es) : UB_OOB;   // (nothing is fetched for the padding)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        ub_u4& d = raw[sec * NTS + tl][j];
+        ub_u4& d = raw[SL][sec * NTS + tl][j];
         if (BF) { const ub_u2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(off + j * pb), 0, 0); d[0] = u[0]; d[1] = u[1]; }
         else d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + j * pb), 0, 0);
       }
     }
   };
-  auto issue_loads = [&](const int k) {
+  auto issue_loads = [&](const int k, auto slotc) {
     const long img = img0 + k / SPI;
     const int tx = (k / NBI) % tiles_x, b = k % NBI;
-    if (a.bf0) load_view(UbBool<true>{}, 0, img, tx, b); else load_view(UbBool<false>{}, 0, img, tx, b);
-    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, 1, img, tx, b); else load_view(UbBool<false>{}, 1, img, tx, b); }
+    if (a.bf0) load_view(UbBool<true>{}, slotc, 0, img, tx, b); else load_view(UbBool<false>{}, slotc, 0, img, tx, b);
+    if (TWO) { if (a.bf1) load_view(UbBool<true>{}, slotc, 1, img, tx, b); else load_view(UbBool<false>{}, slotc, 1, img, tx, b); }
   };
   // activation (folded BatchNorm affine, ReLU), rounding to bf16, transposition to channels-last, LDS
-  auto commit_view = [&](auto bfc, const int sec, const int tx, const int b) {
+  auto commit_view = [&](auto bfc, auto slotc, const int sec, const int tx, const int b) {
     constexpr bool BF = decltype(bfc)::value;
+    constexpr int SL = decltype(slotc)::value;
     const float flo = (sec ? a.relu1 : a.relu0) ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int tl = 0; tl < NTS; ++tl) {
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
       float4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const ub_u4& d = raw[sec * NTS + tl][j];
+        const ub_u4& d = raw[SL][sec * NTS + tl][j];
         const unsigned ux = d[0], uy = d[1];
         if (BF) v[j] = make_float4(ua_lo(ux), ua_hi(ux), ua_lo(uy), ua_hi(uy));
         else { const unsigned uz = d[2], uw = d[3];
@@ -224,13 +230,17 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
       unsigned vo[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) vo[nb] = vout[nb] + (unsigned)(((b * RB + rr) * a.Wd + tx * TW) * eo);   // (UB_OOB stays out of range)
+      // the four 16-pixel blocks of the row as independent accumulation chains: all MFMAs are issued before the first
+      // epilogue reads an accumulator (a block at a time, 34 % of the wave cycles were issue stalls on MFMA results)
+      ub_f4 acc[TW / 16][NB];
 #pragma unroll
-      for (int cb = 0; cb < TW / 16; ++cb) {
-        ub_f4 acc[NB];
+      for (int cb = 0; cb < TW / 16; ++cb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int cb = 0; cb < TW / 16; ++cb) {
           const char* ap = lds + (abase[m] + rr * (LDT * CP * 2)) + cb * 16 * CP * 2;
           ub_bf8 af;
           if (CP == 4) {                                  // 8-byte aligned only
@@ -241,12 +251,14 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
             af = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const uint4*>(ap));
           }
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[m][nb], acc[nb], 0, 0, 0);
+          for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[m][nb], acc[cb][nb], 0, 0, 0);
         }
-        // D[pixel 4*lg + r][co = lp]
+      // D[pixel 4*lg + r][co = lp]
+#pragma unroll
+      for (int cb = 0; cb < TW / 16; ++cb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const float c0 = acc[nb][0], c1 = acc[nb][1], c2 = acc[nb][2], c3 = acc[nb][3];
+          const float c0 = acc[cb][nb][0], c1 = acc[cb][nb][1], c2 = acc[cb][nb][2], c3 = acc[cb][nb][3];
           if (BFO) {
             const ub_u2 pk = {ub_pack2(c0, c1), ub_pack2(c2, c3)};
             __builtin_amdgcn_raw_buffer_store_b64(pk, ro, (int)(vo[nb] + cb * 32), 0, 0);
@@ -257,7 +269,6 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
           s1[nb] += (c0 + c1) + (c2 + c3);
           s2[nb] += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
         }
-      }
     }
   };
   auto load_affine = [&](const long img) {                // folded BatchNorm affine of the image's group -> LDS
@@ -276,19 +287,15 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     }
   };
 
-  if (nstage > 0) { load_affine(img0); issue_loads(0); }
-#pragma unroll 1
-  for (int k = 0; k < nstage; ++k) {
+  auto stage = [&](const int k, auto slotc) {
     const long img = img0 + k / SPI;
     const int tx = (k / NBI) % tiles_x, b = k % NBI;
     __syncthreads();                                      // stage k-1's matrix phase is done with the tile; aff is in place
-    if (a.bf0) commit_view(UbBool<true>{}, 0, tx, b); else commit_view(UbBool<false>{}, 0, tx, b);
-    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, 1, tx, b); else commit_view(UbBool<false>{}, 1, tx, b); }
+    if (a.bf0) commit_view(UbBool<true>{}, slotc, 0, tx, b); else commit_view(UbBool<false>{}, slotc, 0, tx, b);
+    if (TWO) { if (a.bf1) commit_view(UbBool<true>{}, slotc, 1, tx, b); else commit_view(UbBool<false>{}, slotc, 1, tx, b); }
     __syncthreads();
-    if (k + 1 < nstage) {
-      issue_loads(k + 1);
-      if ((k + 1) % SPI == 0 && (img + 1) % a.gsize == 0) load_affine(img + 1);     // (every reader of aff is past the barrier)
-    }
+    if (k + PF < nstage) issue_loads(k + PF, slotc);      // (this stage's registers are free again)
+    if (k + 1 < nstage && (k + 1) % SPI == 0 && (img + 1) % a.gsize == 0) load_affine(img + 1);   // (every reader of aff is past the barrier)
     if (a.bfo) matrix_phase(UbBool<true>{}, img, tx, b); else matrix_phase(UbBool<false>{}, img, tx, b);
     if (b == NBI - 1) {
       if (a.stats) {                                      // per-tile BatchNorm statistics from the accumulators
@@ -309,10 +316,16 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
     }
+  };
+  if (nstage > 0) { load_affine(img0); issue_loads(0, UbInt<0>{}); }
+  if (PF > 1 && nstage > 1) issue_loads(1, UbInt<PF - 1>{});
+#pragma unroll 1
+  for (int k0 = 0; k0 < nstage; k0 += PF) {
+    stage(k0, UbInt<0>{});
+    if (PF > 1 && k0 + 1 < nstage) stage(k0 + 1, UbInt<PF - 1>{});
   }
 }
 
-// ------------------------------------------------------------------------------------------------
 // Weight gradient on the bf16 matrix pipe (ub_wgrad3x3_kernel):
 //   dW[co][(ci,ky),kx] = sum_{img,pixel} dy[co][pixel] * act(x)[ci][pixel + (ky-1, kx-1)]
 //   D[m = (ci,ky)][n = co] += A[m][k] * B[k][n],   k = 32 consecutive pixels of an image row, one MFMA per kx:
