@@ -127,7 +127,7 @@ def unet_pmc_traffic(batch, horizon, cin, size):
     if (batch, horizon, cin, size) != (1, 2, 13, 256):
         return None
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r02b_unet_c3_pmc_traffic.json')))['bytes_per_step']
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r02_unet_c3_pmc_traffic.json')))['bytes_per_step']
     except Exception:
         return None
 

@@ -46,3 +46,14 @@ def test_disconnected_graph_and_isolated_nodes():
     A[10, 20] = 1.0
     order = cluster_order([A])
     assert sorted(order.tolist()) == list(range(N))
+
+
+def test_unet_algorithmic_bytes_reproduce_the_survey():
+    """bench.unet_alg_bytes_fwd (per-op in+out accounting of the UNet conv stack at the element sizes the engine stores)
+    gives SURVEY.md 8(d)'s figures when everything is fp32: 29.7 MB for a 13x256x256 tile, 5.85 MB for 1x128x128; the
+    bf16 mode stores fewer bytes, never more."""
+    import bench
+    assert abs(bench.unet_alg_bytes_fwd(13, 256, 'f32') / 1e6 - 29.7) < 0.05
+    assert abs(bench.unet_alg_bytes_fwd(1, 128, 'f32') / 1e6 - 5.85) < 0.01
+    b = bench.unet_alg_bytes_fwd(13, 256, 'bf16')
+    assert 0.5 * 29.7e6 < b < 29.7e6

@@ -18,6 +18,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-unet > $O/pmc_write.json 2> $O/pmc_write.err
 echo "write done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/unet_pmc_fetch -o run -- python3 $R/tools/bench_unet.py --batch 1 --horizon 2 --size 256 --cin 13 --steps 3 --warmup 1 > $O/unet_pmc_fetch.json 2> $O/unet_pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/unet_pmc_write -o run -- python3 $R/tools/bench_unet.py --batch 1 --horizon 2 --size 256 --cin 13 --steps 3 --warmup 1 > $O/unet_pmc_write.json 2> $O/unet_pmc_write.err
+echo "unet pmc done"
+python3 $R/tools/bench_unet_conv.py > $O/unet_conv_layers.txt 2> $O/unet_conv_layers.err
+for b in 1 2 4 8; do python3 $R/tools/bench_unet.py --batch $b --horizon 2 --size 256 --cin 13 --steps 10 --warmup 3 2>/dev/null | tail -1; done > $O/unet_batch_sweep.txt
+echo "unet layers + batch sweep done"
 export MO_OVL_DENSE=1
 rocprofv3 --kernel-trace --output-format csv -d $O/ks_ovl_dense -o run -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-unet > $O/ovl_dense.json 2> $O/ovl_dense.err
 echo "alt timeline done"
