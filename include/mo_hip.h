@@ -313,6 +313,17 @@ int mo_dropout(const float* x, float* y, long n, uint32_t seed, uint32_t thresh,
 /* ReLU backward on a materialised activation y: out = (y > 0) ? dy : 0 (fc layers, unet.py:142-144) */
 int mo_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream);
 
+/* Few-row Linear layers against a large weight matrix in the bf16 mode (Encoder.fc1 / Decoder.fc2 of unet.py:138-173 at
+ * 256-pixel tiles): "3 x bf16" split products on the bf16 matrix pipe, ~1.5e-5 relative per product (csrc/unet_fc.hpp).
+ * P <= 144 rows; reduction length % 8 == 0; ws: mo_fc3_ws_floats(P, reduction length, output columns).
+ *   mo_fc3_fwd:      out[P][N] = relu?(x[P][K] W[N][K]^T + b)      (b may be NULL)
+ *   mo_fc3_bwd_data: din[P][K] = dout[P][N] W[N][K] */
+int mo_fc3_supported(long P, int R, int C);
+long mo_fc3_ws_floats(long P, int R, int C);
+int mo_fc3_fwd(const float* x, long P, int K, const float* W, const float* b, int N, int relu, float* out, float* ws,
+               void* stream);
+int mo_fc3_bwd_data(const float* dout, long P, int N, const float* W, int K, float* din, float* ws, void* stream);
+
 /* ---- input rasters (the step in front of the path; BlackMarbleDataset's per-image transform, utils.py:35-38,59-64):
  * raw (n, h, w) radiance -> out (n, oh, ow): fill_value -> 0, bilinear antialiased resize (what torchvision 0.18's
  * transforms.Resize does to a float tensor: F.interpolate(mode='bilinear', align_corners=False, antialias=True)), then

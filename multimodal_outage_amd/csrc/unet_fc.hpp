@@ -1,0 +1,159 @@
+// Few-row Linear layers against a large fp32 weight matrix (Encoder.fc1 of config 3: 134 rows x 16384 -> 4096, a 268 MB
+// matrix) in the bf16 mode: "3 x bf16" products on the bf16 matrix pipe.
+//   w = w_hi + w_lo + O(2^-17 |w|),  w_hi = bf16(w), w_lo = bf16(w - w_hi)     (likewise x)
+//   x * w ~= x_hi * w_hi + x_hi * w_lo + x_lo * w_hi                            (the dropped x_lo * w_lo is 2^-18 relative)
+// three v_mfma_f32_16x16x32_bf16 per tile step with fp32 accumulation: ~1.5e-5 relative per product instead of the 2^-9 of
+// a plain bf16 product, at 1/5 of the exact-fp32 MFMA's time -- the exact kernels were compute bound (18 GFLOP per pass at
+// 30 % of the 157 TFLOP/s fp32 peak: 380 us against the 54 us the 268 MB take from HBM).  The weight matrix is read ONCE as
+// fp32 and split in registers; the few-row operand is split beforehand into two bf16 matrices (ufc_split_kernel) and staged
+// through LDS, shared by the four waves of a workgroup.
+//   WMODE 0 (forward):        out[p][n] = sum_k x[p][k]    * W[n][k]      a wave owns 16 rows n of W, streams k
+//   WMODE 1 (data gradient):  din[p][c] = sum_n dout[p][n] * W[n][c]      a wave owns 16 columns c of W, streams rows n
+// Split-K over gridDim.y: slab[ks][p][col] partial sums, folded (+ bias, ReLU) by ufc_reduce_kernel in a fixed order.
+#pragma once
+#include "unet_bf16.hpp"
+
+#define UFC_KC 128                       // reduction elements per staged chunk (4 MFMA steps of 32)
+#define UFC_LD (UFC_KC + 8)              // LDS row stride of the few-row operand (bf16 elements): 272 B, conflict-free b128 reads
+#define UFC_MB 9                         // 16-row blocks of the few-row operand: P <= 144 (134 = 67 counties x 2 days)
+
+struct UfcArgs {
+  const unsigned short* ah;              // few-row operand, hi / lo halves: bf16 [P][R] (R = reduction length)
+  const unsigned short* al;
+  const float* W;                        // WMODE 0: [C][R] (row = output column);  WMODE 1: [R][C]
+  float* slab;                           // [gridDim.y][P][C]
+  int P, R, C;                           // rows, reduction length, output columns
+  int chunks_per_split;                  // chunks of UFC_KC per workgroup
+};
+
+__global__ void ufc_split_kernel(const float* __restrict__ x, long n, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float4 v = *reinterpret_cast<const float4*>(x + i);
+  const unsigned h0 = ub_pack2(v.x, v.y), h1 = ub_pack2(v.z, v.w);
+  const unsigned l0 = ub_pack2(v.x - ua_lo(h0), v.y - ua_hi(h0)), l1 = ub_pack2(v.z - ua_lo(h1), v.w - ua_hi(h1));
+  *reinterpret_cast<uint2*>(hi + i) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(lo + i) = make_uint2(l0, l1);
+}
+
+__global__ void ufc_reduce_kernel(const float* __restrict__ slab, long stride, int nz, const float* __restrict__ bias, int C,
+                                  int relu, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = bias ? bias[i % C] : 0.f;
+  for (int z = 0; z < nz; ++z) s += slab[(long)z * stride + i];
+  out[i] = relu ? fmaxf(s, 0.f) : s;
+}
+
+// 8 fp32 -> hi / lo bf16 fragments
+__device__ __forceinline__ void ufc_split8(const float (&w)[8], ub_bf8& hi, ub_bf8& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = ub_pack2(w[2 * i], w[2 * i + 1]);
+    l[i] = ub_pack2(w[2 * i] - ua_lo(h[i]), w[2 * i + 1] - ua_hi(h[i]));
+  }
+  hi = __builtin_bit_cast(ub_bf8, make_uint4(h[0], h[1], h[2], h[3]));
+  lo = __builtin_bit_cast(ub_bf8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+template <int WMODE, int MB>             // MB: 16-row blocks of the few-row operand (P <= 16 * MB)
+__global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];      // [2][MB*16][UFC_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
+  constexpr int ROWS = MB * 16;
+  constexpr int NI = (ROWS * (UFC_KC / 8) + 255) / 256;                    // 16-byte pieces of a chunk per thread and half
+  unsigned short* xh = xs;
+  unsigned short* xl = xs + ROWS * UFC_LD;
+  const int c0 = (blockIdx.x * 4 + wave) * 16;                             // this wave's 16 output columns
+  const long r_begin = (long)blockIdx.y * a.chunks_per_split * UFC_KC;
+  const int nchunk = (int)min((long)a.chunks_per_split, (a.R - r_begin + UFC_KC - 1) / UFC_KC);
+  const __amdgpu_buffer_rsrc_t rh = ub_rsrc(a.ah, (long)a.P * a.R * 2), rl = ub_rsrc(a.al, (long)a.P * a.R * 2);
+  const __amdgpu_buffer_rsrc_t rw = ub_rsrc(a.W, (long)a.R * a.C * 4);
+
+  ub_f4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
+
+  // software pipeline as in unet_bf16.hpp: chunk ch+1's loads (weight fragments: 4 steps x 8 fp32 per lane; the few-row
+  // operand's 16-byte pieces) are issued in front of chunk ch's matrix work and wait in registers
+  float wreg[4][8];
+  ub_u4 xrh[NI], xrl[NI];
+  int xsrc[NI], xdst[NI];                                                  // element offset in the operand (chunk 0) / in LDS
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int i = tid + 256 * it;
+    const int row = i / (UFC_KC / 8), seg = i - row * (UFC_KC / 8);
+    const bool ok = i < ROWS * (UFC_KC / 8);
+    xdst[it] = ok ? row * UFC_LD + 8 * seg : -1;
+    xsrc[it] = (ok && row < a.P) ? row * a.R + 8 * seg : -1;
+  }
+  auto load_chunk = [&](const int ch) {
+    const long r0 = r_begin + (long)ch * UFC_KC;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long r = r0 + 32 * s + 8 * lg;                                 // first of this lane's 8 reduction indices
+      if (WMODE == 0) {                                                    // W[c0 + lp][r .. r+7]: 32 contiguous bytes
+        const bool ok = (c0 + lp) < a.C && r < a.R;                        // (R % 8 == 0)
+        const unsigned off = ok ? (unsigned)(((long)(c0 + lp) * a.R + r) * 4) : UB_OOB;
+        const ub_u4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0);
+        const ub_u4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(off + 16), 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wreg[s][j] = __uint_as_float(u0[j]); wreg[s][4 + j] = __uint_as_float(u1[j]); }
+      } else {                                                             // W[r + j][c0 + lp]: 8 rows of the matrix
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = (c0 + lp) < a.C && (r + j) < a.R;
+          const unsigned off = ok ? (unsigned)(((r + j) * a.C + c0 + lp) * 4) : UB_OOB;
+          wreg[s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)off, 0, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {                                      // rows >= P and reduction indices >= R read zero
+      const int seg8 = (xdst[it] >= 0) ? (xdst[it] % UFC_LD) : 0;
+      const unsigned off = (xsrc[it] >= 0 && r0 + seg8 < a.R) ? (unsigned)(((long)xsrc[it] + r0) * 2) : UB_OOB;
+      xrh[it] = __builtin_amdgcn_raw_buffer_load_b128(rh, (int)off, 0, 0);
+      xrl[it] = __builtin_amdgcn_raw_buffer_load_b128(rl, (int)off, 0, 0);
+    }
+  };
+  if (nchunk > 0) load_chunk(0);
+#pragma unroll 1
+  for (int ch = 0; ch < nchunk; ++ch) {
+    __syncthreads();                                                       // previous chunk's reads of xs are done
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+      if (xdst[it] >= 0) {
+        *reinterpret_cast<ub_u4*>(&xh[xdst[it]]) = xrh[it];
+        *reinterpret_cast<ub_u4*>(&xl[xdst[it]]) = xrl[it];
+      }
+    ub_bf8 wh[4], wl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ufc_split8(wreg[s], wh[s], wl[s]);
+    __syncthreads();
+    if (ch + 1 < nchunk) load_chunk(ch + 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int o = (mb * 16 + lp) * UFC_LD + 32 * s + 8 * lg;
+        const ub_bf8 ah = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const ub_u4*>(&xh[o]));
+        const ub_bf8 al = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const ub_u4*>(&xl[o]));
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[s], acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[s], acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[s], acc[mb], 0, 0, 0);
+      }
+    }
+  }
+  // D[row = 4*lg + r][col = lp] of every block -> slab[ks][p][c]
+  float* out = a.slab + (long)blockIdx.y * a.P * a.C;
+  if (c0 + lp < a.C) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = mb * 16 + 4 * lg + r;
+        if (p < a.P) out[(long)p * a.C + c0 + lp] = acc[mb][r];
+      }
+  }
+}

@@ -11,6 +11,7 @@
 #include "unet_direct.hpp"
 #include "unet_thin.hpp"
 #include "unet_bf16.hpp"
+#include "unet_fc.hpp"
 #include "../../include/mo_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
@@ -750,6 +751,58 @@ extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int g
                                     void* stream) {
   return mo_group_bn_finalize2(stats, n_img, C, gsize, HW, ntile, gamma, beta, running_mean, running_var, momentum, eps,
                                training, scale, shift, mean, rstd, nullptr, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// few-row Linear layers on the bf16 matrix pipe with 3 x bf16 split products (unet_fc.hpp)
+// ------------------------------------------------------------------------------------------------
+static void ufc_plan(long P, int R, int C, int& ks, int& cps) {
+  const int nx = mo_cdiv(C, 64), chunks = mo_cdiv(R, UFC_KC);
+  int want = 512 / nx; if (want < 1) want = 1; if (want > chunks) want = chunks;
+  cps = mo_cdiv(chunks, want);
+  ks = mo_cdiv(chunks, cps);
+}
+extern "C" int mo_fc3_supported(long P, int R, int C) {
+  return P > 0 && P <= 16 * UFC_MB && R > 0 && C > 0 && (R % 8) == 0 && (C % 4) == 0 && (long)R * C * 4 < (1L << 31) &&
+         P * (long)R * 2 < (1L << 31);
+}
+extern "C" long mo_fc3_ws_floats(long P, int R, int C) {
+  int ks, cps; ufc_plan(P, R, C, ks, cps);
+  return P * (long)R + (long)ks * P * C + 64;          // hi + lo halves of the few-row operand (bf16), split-K slabs
+}
+template <int WMODE>
+static int ufc_run(const float* a, long P, int R, const float* W, int C, const float* bias, int relu, float* out, float* ws,
+                   hipStream_t st) {
+  unsigned short* hi = reinterpret_cast<unsigned short*>(ws);
+  unsigned short* lo = hi + P * (long)R;
+  float* slab = ws + P * (long)R;
+  const long n = P * (long)R;
+  hipLaunchKernelGGL(ufc_split_kernel, dim3(mo_cdiv(n / 4, 256)), dim3(256), 0, st, a, n, hi, lo);
+  int ks, cps; ufc_plan(P, R, C, ks, cps);
+  UfcArgs A;
+  A.ah = hi; A.al = lo; A.W = W; A.slab = slab; A.P = (int)P; A.R = R; A.C = C; A.chunks_per_split = cps;
+  const size_t lds = (size_t)2 * UFC_MB * 16 * UFC_LD * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ufc_kernel<WMODE, UFC_MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB>), dim3(mo_cdiv(C, 64), ks), dim3(256), lds, st, A);
+  const long no = P * (long)C;
+  hipLaunchKernelGGL(ufc_reduce_kernel, dim3(mo_cdiv(no, 256)), dim3(256), 0, st, slab, no, ks, bias, C, relu, out, no);
+  return mo_launch_status();
+}
+extern "C" int mo_fc3_fwd(const float* x, long P, int K, const float* W, const float* b, int N, int relu, float* out,
+                          float* ws, void* stream) {
+  MO_CHECK_ARG(x && W && out && ws && mo_fc3_supported(P, K, N));
+  MO_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)ws) & 15) == 0);
+  return ufc_run<0>(x, P, K, W, N, b, relu, out, ws, ST(stream));
+}
+extern "C" int mo_fc3_bwd_data(const float* dout, long P, int N, const float* W, int K, float* din, float* ws, void* stream) {
+  MO_CHECK_ARG(dout && W && din && ws && mo_fc3_supported(P, N, K));
+  MO_CHECK_ARG((((uintptr_t)dout) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)ws) & 15) == 0);
+  return ufc_run<1>(dout, P, N, W, K, nullptr, 0, din, ws, ST(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

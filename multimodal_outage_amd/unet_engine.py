@@ -222,30 +222,21 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
     return dgrad(dy1, p[pre + '.double_conv.0.weight'], dx_bf)
 
 
-# Experiment kept behind a switch (MO_FC_BF16=1; default off): in the bf16 mode the products against the two 268 MB FC
-# weight matrices of config 3 on the bf16 matrix pipe (decoder fc2 forward, data gradients of decoder fc2 / encoder fc1; a
-# bf16 copy of the weight per step).  Measured 9.41 -> 9.09 ms per config-3 step, but the st_gnn gradient of the config-3
-# golden moves from 0.69 to 0.78 relative L2 from the float64 reference (the perturbation of the bottleneck is amplified
-# ~7x per DoubleConv stage of that test's backward) -- not worth 3 %.
-FC_BF16_MIN = (1 << 24) if os.environ.get('MO_FC_BF16', '0') == '1' else (1 << 62)
-FC_BF16_DGRAD = True
+# bf16 mode: Linear layers against weight matrices of at least this many elements (Encoder.fc1 16384 -> 4096 and Decoder.fc2
+# 1024 -> 16384 of config 3) run as "3 x bf16" split products on the bf16 matrix pipe (mo_fc3_*: ~1.5e-5 relative per product,
+# 3x faster than the exact-fp32 MFMA, which is compute bound on them).  MO_FC3=0: exact fp32 everywhere (A/B switch).
+# (A plain bf16 product was measured too: 0.3 ms faster still, but it moved the deep-stage gradient distance of the config-3
+# golden from 0.69 to 0.78 -- the 3-way split leaves it where it was.)
+FC3_MIN = (1 << 22) if os.environ.get('MO_FC3', '1') != '0' else (1 << 62)
 
 
-def _to_bf16(t):
-    y = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
-    L.call('mo_f32_to_bf16', L.ptr(t), L.ptr(y), t.numel(), L.stream())
-    return y
-
-
-def _fc_fwd(x, W, b, relu, wbf=None):
+def _fc_fwd(x, W, b, relu, math=False):
     P, Ci = x.shape
     Co = W.shape[0]
     out = _empty(P, Co, dev=x.device)
-    if wbf is not None:
-        # bf16 mode, many output columns: bf16 matrix pipe, fp32 accumulation, bias + ReLU in the epilogue (the exact-fp32 MFMA
-        # needs ~200 us for the 18 GFLOP of a few-row product against the 268 MB weight matrix; its HBM time is 54 us)
-        L.call('mo_gemm_bf16_ex', L.ptr(_to_bf16(x)), Ci, L.ptr(wbf), Ci, 0, L.ptr(out), Co, P, Co, Ci, 0, None, L.ptr(b),
-               1 if relu else 0, None, L.stream())
+    if math and W.numel() >= FC3_MIN and L.load().mo_fc3_supported(P, Ci, Co):
+        ws = torch.empty(L.load().mo_fc3_ws_floats(P, Ci, Co), device=x.device, dtype=torch.float32)
+        L.call('mo_fc3_fwd', L.ptr(x), P, Ci, L.ptr(W), L.ptr(b), Co, 1 if relu else 0, L.ptr(out), L.ptr(ws), L.stream())
         return out
     if Ci >= 2048 and P <= 1024:        # few rows x long K: split-K (the tile grid alone would be ~20 workgroups)
         ws = torch.empty(L.load().mo_linear_splitk_ws_floats(P, Co, Ci), device=x.device, dtype=torch.float32)
@@ -267,25 +258,11 @@ def _dropout(x, seed, thresh, scale):
 
 def fc_block_fwd(p, pre, x, drop, math=False):
     """unet.py:138-149 / :162-173: relu(fc1) -> dropout -> relu(fc2) on rows of x.  math (bf16 mode): the products against
-    the two large weight matrices on the bf16 matrix pipe where the result's tiles fill the chip -- only with MO_FC_BF16=1
-    (see FC_BF16_MIN above); a bf16 copy of such a weight is made once per step and kept for
-    the backward pass."""
-    wbf = {}
-
-    def big(W, n_cols):                  # (the product's 128 x 128 result tiles must fill the chip: >= 128 of them)
-        return (math and W.numel() >= FC_BF16_MIN and ((x.shape[0] + 127) // 128) * (n_cols // 128) >= 128
-                and W.shape[0] % 8 == 0 and W.shape[1] % 8 == 0)
-
-    def copy_of(key):
-        if key not in wbf:
-            wbf[key] = _to_bf16(p[key])
-        return wbf[key]
-
-    W1, W2 = p[pre + '.fc1.weight'], p[pre + '.fc2.weight']
-    h1 = _fc_fwd(x, W1, p[pre + '.fc1.bias'], True, copy_of(pre + '.fc1.weight') if big(W1, W1.shape[0]) else None)
+    the large weight matrices as 3 x bf16 split products (FC3_MIN above)."""
+    h1 = _fc_fwd(x, p[pre + '.fc1.weight'], p[pre + '.fc1.bias'], True, math)
     d1 = _dropout(h1, *drop)
-    h2 = _fc_fwd(d1, W2, p[pre + '.fc2.bias'], True, copy_of(pre + '.fc2.weight') if big(W2, W2.shape[0]) else None)
-    return dict(pre=pre, x=x, h1=h1, d1=d1, h2=h2, drop=drop, math=math, wbf=wbf), h2
+    h2 = _fc_fwd(d1, p[pre + '.fc2.weight'], p[pre + '.fc2.bias'], True, math)
+    return dict(pre=pre, x=x, h1=h1, d1=d1, h2=h2, drop=drop, math=math), h2
 
 
 def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True, lane=None):
@@ -310,14 +287,9 @@ def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True, lane=None):
         if not need_in:
             return None
         din = _empty(P, Ci, dev=dev)
-        if (FC_BF16_DGRAD and sv.get('math') and W.numel() >= FC_BF16_MIN and ((P + 127) // 128) * (Ci // 128) >= 128
-                and Co % 8 == 0 and Ci % 8 == 0):
-            # din[P][Ci] = dout[P][Co] . W[Co][Ci]: the weight is the k-major operand as it lies (b_krows = 1)
-            wb = sv['wbf'].get(wkey)
-            if wb is None:
-                wb = _to_bf16(W)
-            L.call('mo_gemm_bf16_ex', L.ptr(_to_bf16(dout)), Co, L.ptr(wb), Ci, 1, L.ptr(din), Ci, P, Ci, Co, 0, None, None, 0,
-                   None, st)
+        if sv.get('math') and W.numel() >= FC3_MIN and lib.mo_fc3_supported(P, Co, Ci):
+            wsd = torch.empty(lib.mo_fc3_ws_floats(P, Co, Ci), device=dev, dtype=torch.float32)
+            L.call('mo_fc3_bwd_data', L.ptr(dout), P, Co, L.ptr(W), Ci, L.ptr(din), L.ptr(wsd), st)
             return din
         if Co >= 2048 and P <= 1024:
             wsd = torch.empty(lib.mo_linear_splitk_ws_floats(P, Ci, Co), device=dev, dtype=torch.float32)

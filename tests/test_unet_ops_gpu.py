@@ -299,3 +299,25 @@ def test_dropout_mask(L):
     y2 = torch.empty(n, device='cuda')
     L.call('mo_dropout', L.ptr(dev(x)), L.ptr(y2), n, 77, thresh, 1.0 / 0.7, L.stream())
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('P,K,N', [(134, 16384, 4096), (134, 1024, 16384), (7, 256, 128), (144, 4096, 264), (33, 520, 72)])
+def test_fc_three_way_bf16_split(L, P, K, N):
+    """mo_fc3_fwd / mo_fc3_bwd_data (csrc/unet_fc.hpp): few-row Linear layers with "3 x bf16" split products on the bf16
+    matrix pipe against the float64 product: 5e-5 of the result's scale (a plain bf16 product would sit at ~2e-3);
+    ragged row counts, reduction lengths that are not a multiple of the 128-element chunk, column counts that are not a
+    multiple of a workgroup's 64."""
+    lib = L.load()
+    x = rand(31, (P, K)); W = rand(32, (N, K)) / np.sqrt(K); b = rand(33, (N,)); dout = rand(34, (P, N))
+    xd, Wd, bd, dd = dev(x), dev(W), dev(b), dev(dout)
+    assert lib.mo_fc3_supported(P, K, N) == 1 and lib.mo_fc3_supported(P, N, K) == 1
+    for relu in (0, 1):
+        out = torch.full((P, N), float('nan'), device='cuda')
+        ws = torch.empty(lib.mo_fc3_ws_floats(P, K, N), device='cuda')
+        L.call('mo_fc3_fwd', L.ptr(xd), P, K, L.ptr(Wd), L.ptr(bd), N, relu, L.ptr(out), L.ptr(ws), L.stream())
+        ref = x.double() @ W.double().t() + b.double()
+        close(out, torch.relu(ref) if relu else ref, tol=5e-5, what='fc3 forward')
+    din = torch.full((P, K), float('nan'), device='cuda')
+    ws = torch.empty(lib.mo_fc3_ws_floats(P, N, K), device='cuda')
+    L.call('mo_fc3_bwd_data', L.ptr(dd), P, N, L.ptr(Wd), K, L.ptr(din), L.ptr(ws), L.stream())
+    close(din, dout.double() @ W.double(), tol=5e-5, what='fc3 data gradient')
