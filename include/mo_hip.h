@@ -323,6 +323,11 @@ long mo_fc3_ws_floats(long P, int R, int C);
 int mo_fc3_fwd(const float* x, long P, int K, const float* W, const float* b, int N, int relu, float* out, float* ws,
                void* stream);
 int mo_fc3_bwd_data(const float* dout, long P, int N, const float* W, int K, float* din, float* ws, void* stream);
+/*   mo_fc3_bwd_weight: dW[N][K] = dout[P][N]^T x[P][K], db[N] = column sums of dout (may be NULL); P <= 160;
+ *   ws: mo_fc3_wgrad_ws_floats(P, N, K) */
+long mo_fc3_wgrad_ws_floats(long P, int N, int C);
+int mo_fc3_bwd_weight(const float* dout, long P, int N, const float* x, int C, float* dW, float* db, float* ws,
+                      void* stream);
 
 /* ---- input rasters (the step in front of the path; BlackMarbleDataset's per-image transform, utils.py:35-38,59-64):
  * raw (n, h, w) radiance -> out (n, oh, ow): fill_value -> 0, bilinear antialiased resize (what torchvision 0.18's

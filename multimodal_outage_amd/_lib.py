@@ -83,6 +83,8 @@ SIGNATURES = {
     'mo_fc3_ws_floats': (i64, [i64, i32, i32]),
     'mo_fc3_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, vp]),
     'mo_fc3_bwd_data': (i32, [vp, i64, i32, vp, i32, vp, vp, vp]),
+    'mo_fc3_wgrad_ws_floats': (i64, [i64, i32, i32]),
+    'mo_fc3_bwd_weight': (i32, [vp, i64, i32, vp, i32, vp, vp, vp, vp]),
     'mo_nchw_stats': (i32, [vp, i64, i32, i64, i32, vp, vp]),
     'mo_group_bn_finalize': (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     'mo_group_bn_finalize2': (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp]),

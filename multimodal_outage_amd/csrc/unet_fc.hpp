@@ -157,3 +157,111 @@ __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
       }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers: dW[n][c] = sum_p dout[p][n] * x[p][c]  (k = p: 134 rows, padded to 160), output
+// bound on the 268 MB of dW.  Both operands are needed p-contiguous: ufc_tsplit_kernel writes the hi / lo halves of a
+// [P][Q] fp32 matrix transposed, [Q][UFC_PP] bf16 (and the column sums: the bias gradient).  A wave keeps the fragments
+// of its 16 columns c (x^T, 5 steps x hi/lo) in registers and sweeps the rows n; the dout^T blocks of 64 rows are staged
+// in LDS for the four waves of a workgroup.
+// ------------------------------------------------------------------------------------------------
+#define UFC_PP 160                       // padded row count of the transposed halves (5 MFMA steps of 32)
+#define UFC_NS 5
+#define UFC_TLD (UFC_PP + 8)             // LDS row stride of a staged dout^T row (bf16)
+
+// out_hi/out_lo[q][p] = split(in[p][q]); colsum[q] = sum_p in[p][q] (may be NULL).  One thread per column q.
+__global__ void ufc_tsplit_kernel(const float* __restrict__ in, int P, int Q, unsigned short* __restrict__ hi,
+                                  unsigned short* __restrict__ lo, float* __restrict__ colsum) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q) return;
+  float s = 0.f;
+  for (int p0 = 0; p0 < UFC_PP; p0 += 8) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = p0 + 2 * i;
+      const float a = (p < P) ? in[(long)p * Q + q] : 0.f, b = (p + 1 < P) ? in[(long)(p + 1) * Q + q] : 0.f;
+      s += a + b;
+      h[i] = ub_pack2(a, b);
+      l[i] = ub_pack2(a - ua_lo(h[i]), b - ua_hi(h[i]));
+    }
+    *reinterpret_cast<uint4*>(hi + (long)q * UFC_PP + p0) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(lo + (long)q * UFC_PP + p0) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+  if (colsum) colsum[q] = s;
+}
+
+struct UfcWArgs {
+  const unsigned short* dh; const unsigned short* dl;     // dout^T halves [N][UFC_PP]
+  const unsigned short* xh; const unsigned short* xl;     // x^T halves    [C][UFC_PP]
+  float* dW;                                              // [N][C]
+  int N, C;
+  int nrows_per_wg;                                       // rows n swept by one workgroup (multiple of 64)
+};
+
+__global__ __launch_bounds__(256, 2) void ufc_wgrad_kernel(UfcWArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short ds[2][64 * UFC_TLD];      // hi / lo halves of 64 rows of dout^T
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
+  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  const int n_begin = blockIdx.y * a.nrows_per_wg;
+  const int n_end = min(n_begin + a.nrows_per_wg, a.N);
+  // B fragments: this lane's column c0 + lp, pixels... rows p = 32 s + 8 lg .. +7 of x^T
+  ub_bf8 bh[UFC_NS], bl[UFC_NS];
+  {
+    const bool ok = c0 + lp < a.C;
+    const long o = (long)min(c0 + lp, a.C - 1) * UFC_PP + 8 * lg;
+#pragma unroll
+    for (int s = 0; s < UFC_NS; ++s) {
+      uint4 vh = *reinterpret_cast<const uint4*>(a.xh + o + 32 * s), vl = *reinterpret_cast<const uint4*>(a.xl + o + 32 * s);
+      if (!ok) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+      bh[s] = __builtin_bit_cast(ub_bf8, vh); bl[s] = __builtin_bit_cast(ub_bf8, vl);
+    }
+  }
+  // staging of a 64-row group of dout^T: 64 rows x 160 bf16 = 20 sixteen-byte pieces per row and half -> 5 per thread
+  constexpr int NI = 64 * (UFC_PP / 8) / 256;
+  uint4 rh[NI], rl[NI];
+  auto load_group = [&](const int n0) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + 256 * it, row = i / (UFC_PP / 8), seg = i - row * (UFC_PP / 8);
+      const bool ok = n0 + row < a.N;
+      const long o = (long)min(n0 + row, a.N - 1) * UFC_PP + 8 * seg;
+      rh[it] = *reinterpret_cast<const uint4*>(a.dh + o); rl[it] = *reinterpret_cast<const uint4*>(a.dl + o);
+      if (!ok) { rh[it] = make_uint4(0u, 0u, 0u, 0u); rl[it] = rh[it]; }
+    }
+  };
+  if (n_begin < n_end) load_group(n_begin);
+#pragma unroll 1
+  for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + 256 * it, row = i / (UFC_PP / 8), seg = i - row * (UFC_PP / 8);
+      *reinterpret_cast<uint4*>(&ds[0][row * UFC_TLD + 8 * seg]) = rh[it];
+      *reinterpret_cast<uint4*>(&ds[1][row * UFC_TLD + 8 * seg]) = rl[it];
+    }
+    __syncthreads();
+    if (n0 + 64 < n_end) load_group(n0 + 64);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      ub_f4 acc = (ub_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < UFC_NS; ++s) {
+        const int o = (nb * 16 + lp) * UFC_TLD + 32 * s + 8 * lg;
+        const ub_bf8 ah = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const uint4*>(&ds[0][o]));
+        const ub_bf8 al = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const uint4*>(&ds[1][o]));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[s], acc, 0, 0, 0);
+      }
+      // D[row n = 4*lg + r][col c = lp]
+      if (c0 + lp < a.C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + nb * 16 + 4 * lg + r;
+          if (n < a.N) a.dW[(long)n * a.C + c0 + lp] = acc[r];
+        }
+      }
+    }
+  }
+}

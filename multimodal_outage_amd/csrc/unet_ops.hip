@@ -793,6 +793,27 @@ static int ufc_run(const float* a, long P, int R, const float* W, int C, const f
   hipLaunchKernelGGL(ufc_reduce_kernel, dim3(mo_cdiv(no, 256)), dim3(256), 0, st, slab, no, ks, bias, C, relu, out, no);
   return mo_launch_status();
 }
+extern "C" long mo_fc3_wgrad_ws_floats(long P, int N, int C) { return ((long)N + C) * UFC_PP + 64; }   // two bf16 halves each
+extern "C" int mo_fc3_bwd_weight(const float* dout, long P, int N, const float* x, int C, float* dW, float* db, float* ws,
+                                 void* stream) {
+  MO_CHECK_ARG(dout && x && dW && ws && P > 0 && P <= UFC_PP && N > 0 && C > 0 && (((uintptr_t)ws) & 15) == 0);
+  hipStream_t st = ST(stream);
+  unsigned short* dh = reinterpret_cast<unsigned short*>(ws);
+  unsigned short* dl = dh + (long)N * UFC_PP;
+  unsigned short* xh = dl + (long)N * UFC_PP;
+  unsigned short* xl = xh + (long)C * UFC_PP;
+  hipLaunchKernelGGL(ufc_tsplit_kernel, dim3(mo_cdiv(N, 256)), dim3(256), 0, st, dout, (int)P, N, dh, dl, db);
+  hipLaunchKernelGGL(ufc_tsplit_kernel, dim3(mo_cdiv(C, 256)), dim3(256), 0, st, x, (int)P, C, xh, xl, (float*)nullptr);
+  UfcWArgs A;
+  A.dh = dh; A.dl = dl; A.xh = xh; A.xl = xl; A.dW = dW; A.N = N; A.C = C;
+  const int gx = mo_cdiv(C, 64);
+  int gy = 512 / gx; if (gy < 1) gy = 1;
+  int rows = mo_cdiv(mo_cdiv(N, gy), 64) * 64;
+  gy = mo_cdiv(N, rows);
+  A.nrows_per_wg = rows;
+  hipLaunchKernelGGL(ufc_wgrad_kernel, dim3(gx, gy), dim3(256), 0, st, A);
+  return mo_launch_status();
+}
 extern "C" int mo_fc3_fwd(const float* x, long P, int K, const float* W, const float* b, int N, int relu, float* out,
                           float* ws, void* stream) {
   MO_CHECK_ARG(x && W && out && ws && mo_fc3_supported(P, K, N));

@@ -280,6 +280,10 @@ def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True, lane=None):
         db = grads.buf(bkey, (Co,))
 
         def fn():
+            if sv.get('math') and W.numel() >= FC3_MIN and P <= 160:
+                ws = torch.empty(lib.mo_fc3_wgrad_ws_floats(P, Co, Ci), device=dev, dtype=torch.float32)
+                L.call('mo_fc3_bwd_weight', L.ptr(dout), P, Co, L.ptr(inp), Ci, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+                return
             ws = torch.empty(lib.mo_wgrad_ws_floats(Co, Ci, P), device=dev, dtype=torch.float32)
             L.call('mo_conv1x1_bwd_weight', L.ptr(dout), Co, P, L.ptr(inp), Ci, 0, 0, 0, 0, L.ptr(dW), L.ptr(db), L.ptr(ws),
                    L.stream())

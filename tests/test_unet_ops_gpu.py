@@ -321,3 +321,8 @@ def test_fc_three_way_bf16_split(L, P, K, N):
     ws = torch.empty(lib.mo_fc3_ws_floats(P, N, K), device='cuda')
     L.call('mo_fc3_bwd_data', L.ptr(dd), P, N, L.ptr(Wd), K, L.ptr(din), L.ptr(ws), L.stream())
     close(din, dout.double() @ W.double(), tol=5e-5, what='fc3 data gradient')
+    dW = torch.full((N, K), float('nan'), device='cuda'); db = torch.full((N,), float('nan'), device='cuda')
+    ws = torch.empty(lib.mo_fc3_wgrad_ws_floats(P, N, K), device='cuda')
+    L.call('mo_fc3_bwd_weight', L.ptr(dd), P, N, L.ptr(xd), K, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+    close(dW, dout.double().t() @ x.double(), tol=5e-5, what='fc3 weight gradient')
+    close(db, dout.double().sum(0), tol=1e-5, what='fc3 bias gradient')
