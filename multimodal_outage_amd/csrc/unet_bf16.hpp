@@ -49,10 +49,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ub_rsrc(const void* p, long by
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
 }
 
-template <int CP, int NB, int RB, bool TWO>   // padded input channels (4, 8, 16, 32), blocks of 16 output channels, rows per
-                                               // band, TWO: two views of CP/2 channels each (the skip / up concat)
+template <int CP, int NB, int RB, bool TWO, int TW = UB_TW>   // padded input channels (4, 8, 16, 32), blocks of 16 output
+                                               // channels, rows per band, TWO: two views of CP/2 channels each (the skip /
+                                               // up concat), TW: tile width (64; 32 for 32-pixel-wide images)
 __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
-  constexpr int TW = UB_TW, TH = UB_TH, LDT = TW + 8;     // col = x - x0 + 4: whole quads x0-4 .. x0+TW+3 are staged
+  constexpr int TH = UB_TH, LDT = TW + 8;                 // col = x - x0 + 4: whole quads x0-4 .. x0+TW+3 are staged
   constexpr int CPC = CP >= 8 ? CP / 8 : 1;               // 16-byte chunks per pixel
   constexpr int NCH = CP == 4 ? 6 : 9 * CPC;              // k chunks of 8
   constexpr int NM = (NCH + 3) / 4;                       // MFMAs per 16-pixel block and output block

@@ -92,7 +92,10 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
 @pytest.mark.parametrize('n,gs,C0,C1,Co,H,W', [(4, 2, 4, 0, 4, 16, 64), (3, 1, 13, 0, 4, 32, 64), (2, 2, 4, 4, 4, 16, 128),
                                                 (2, 1, 8, 0, 8, 32, 128), (2, 2, 8, 8, 8, 16, 64), (2, 1, 8, 0, 16, 64, 64),
                                                 (2, 1, 16, 16, 16, 16, 64), (3, 3, 16, 0, 32, 16, 64), (2, 1, 16, 16, 32, 32, 64), (2, 1, 20, 0, 32, 32, 64),
-                                                (2, 2, 5, 0, 13, 16, 64), (70, 2, 4, 0, 8, 64, 128), (40, 2, 8, 8, 20, 16, 64)])
+                                                (2, 2, 5, 0, 13, 16, 64), (70, 2, 4, 0, 8, 64, 128), (40, 2, 8, 8, 20, 16, 64),
+                                                # 32-pixel-wide tiles (the 32 x 32 level)
+                                                (3, 1, 16, 0, 32, 32, 32), (2, 2, 32, 0, 32, 32, 32), (2, 1, 32, 0, 16, 16, 32),
+                                                (4, 2, 8, 8, 8, 32, 32), (2, 1, 4, 0, 4, 48, 32)])
 @pytest.mark.parametrize('bf', [0, 1])
 def test_conv3x3_bf16_matrix_pipe(L, n, gs, C0, C1, Co, H, W, bf):
     """MO_BF_MATH: the 3x3 conv, its data gradient (weights read transposed + flipped, MO_W_FLIP) and its weight gradient
@@ -101,6 +104,15 @@ def test_conv3x3_bf16_matrix_pipe(L, n, gs, C0, C1, Co, H, W, bf):
     activations whose fused-multiply-add affine lands on the other side of a bf16 rounding boundary); the unrounded conv
     is checked at the bf16 tolerance.  bf=1: activations stored as bf16 as well."""
     lib = L.load()
+    if W % 64:
+        L.call('mo_unet_set_option', b'ub_min_w', 32)       # (the 32-pixel-wide tiles are off by default)
+    try:
+        _conv3x3_bf16_matrix_pipe(L, lib, n, gs, C0, C1, Co, H, W, bf)
+    finally:
+        L.call('mo_unet_set_option', b'ub_min_w', 64)
+
+
+def _conv3x3_bf16_matrix_pipe(L, lib, n, gs, C0, C1, Co, H, W, bf):
     assert lib.mo_conv3x3_bf16_route(C0 + C1, Co, n, H, W) == 1 and (C1 == 0 or C0 == C1)
     G = n // gs
     rb = lambda t: t.to(torch.bfloat16).float()
@@ -122,7 +134,7 @@ def test_conv3x3_bf16_matrix_pipe(L, n, gs, C0, C1, Co, H, W, bf):
     args_in = (L.ptr(x0d), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1, L.ptr(x1d), C1, C1 * H * W, None, None, 0)
     dt = L.BF_MATH | ((L.BF_IN0 | L.BF_OUT) if bf else 0)
     ntile = lib.mo_conv3x3_stats_tiles2(Ci, Co, n, H, W, dt)
-    assert ntile == (W // 64) * (H // 16)
+    assert ntile == (W // (64 if W % 64 == 0 else 32)) * (H // 16)
     stats = torch.full((n, ntile, Co, 2), float('nan'), device='cuda')
     Wd_ = dev(Wt)
     L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(Wd_), Co, n, H, W, L.ptr(out), Co * H * W, L.ptr(stats), dt, L.stream())
@@ -141,7 +153,7 @@ def test_conv3x3_bf16_matrix_pipe(L, n, gs, C0, C1, Co, H, W, bf):
         L.call('mo_conv3x3_fwd', L.ptr(dyd), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wd_), Ci,
                n, H, W, L.ptr(dcat), Ci * H * W, None, L.BF_MATH | L.W_FLIP | (L.BF_IN0 * bf) | (L.BF_OUT * obf), L.stream())
         close(dcat.float(), dref_q, tol=4e-3 if obf else 1e-4, what='conv bwd data vs bf16-rounded operands')
-    if bf and Co <= 16:
+    if bf and Co <= 16 and W % 64 == 0:
         # weight gradient: dy read straight into the B fragments, the activated input planar in LDS
         Wp = Wt.clone().requires_grad_(True)
         F.conv2d(rb(cat), Wp, None, padding=1).backward(rb(dy))
