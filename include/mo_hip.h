@@ -242,8 +242,8 @@ int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, co
                    int dtypes /* MO_BF_IN0 | MO_BF_IN1 | MO_BF_OUT */, void* stream);
 /* per-image statistics rows mo_conv3x3_fwd writes for this shape (0: none -- run mo_nchw_stats on the output) */
 int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
-/* ... when the call carries `dtypes` (MO_BF_MATH routes to the bf16 matrix-pipe kernel, whose tiles are 16 x 64) */
-int mo_conv3x3_stats_tiles2(int Ci, int Co, long n_img, int H, int Wd, int dtypes);
+/* ... when the call carries `dtypes` and the two views (MO_BF_MATH routes to the bf16 matrix-pipe kernel, whose tiles are 16 x 64) */
+int mo_conv3x3_stats_tiles2(int C0, int C1, int Co, long n_img, int H, int Wd, int dtypes);
 /* 1 when the bf16 matrix-pipe kernels (csrc/unet_bf16.hpp) serve a 3x3 conv of this shape under MO_BF_MATH */
 int mo_conv3x3_bf16_route(int Ci, int Co, long n_img, int H, int Wd);
 /* Wf[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]; the data gradient is mo_conv3x3_fwd(dy, Wf). */

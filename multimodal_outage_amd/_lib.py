@@ -67,7 +67,7 @@ SIGNATURES = {
     'mo_conv3x3_fwd': (i32, [vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32, vp, i32, i64, i32, i32,
                              vp, i64, vp, i32, vp]),
     'mo_conv3x3_stats_tiles': (i32, [i32, i64, i32, i32]),
-    'mo_conv3x3_stats_tiles2': (i32, [i32, i32, i64, i32, i32, i32]),
+    'mo_conv3x3_stats_tiles2': (i32, [i32, i32, i32, i64, i32, i32, i32]),
     'mo_conv3x3_bf16_route': (i32, [i32, i32, i64, i32, i32]),
     'mo_conv3x3_flip_weights': (i32, [vp, i32, i32, vp, vp]),
     'mo_unet_wgrad_ws_floats': (i64, [i32, i32, i64]),

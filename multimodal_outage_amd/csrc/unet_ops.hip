@@ -183,8 +183,11 @@ extern "C" int mo_conv3x3_bf16_route(int Ci, int Co, long n_img, int H, int Wd) 
          n_img > 0 && n_img < (1L << 31) && (long)(Ci > Co ? Ci : Co) * H * Wd * 4 < (1L << 31);
 }
 extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
-extern "C" int mo_conv3x3_stats_tiles2(int Ci, int Co, long n_img, int H, int Wd, int dtypes) {
-  if ((dtypes & MO_BF_MATH) && mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) return (Wd / ub_tw(Wd)) * (H / UB_TH);
+// the second view of the matrix-pipe conv: none, or the equal half of a skip / up concat (4 + 4 .. 16 + 16 channels)
+static bool ub_views_ok(int C0, int C1) { return C1 == 0 || (C0 == C1 && (C0 == 4 || C0 == 8 || C0 == 16)); }
+extern "C" int mo_conv3x3_stats_tiles2(int C0, int C1, int Co, long n_img, int H, int Wd, int dtypes) {
+  if ((dtypes & MO_BF_MATH) && ub_views_ok(C0, C1) && mo_conv3x3_bf16_route(C0 + C1, Co, n_img, H, Wd))
+    return (Wd / ub_tw(Wd)) * (H / UB_TH);
   return mo_conv3x3_stats_tiles(Co, n_img, H, Wd);
 }
 template <int CP, int RB, int TW = UB_TW>
@@ -219,8 +222,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
   const bool al16 = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0)) &&
                     (((uintptr_t)out) & 15) == 0 && (ostride & 3) == 0;
   // (two views: the skip / up concat of equal halves, 4 + 4 .. 16 + 16 channels)
-  if ((dtypes & MO_BF_MATH) && al16 && (C1 == 0 || (C0 == C1 && (C0 == 4 || C0 == 8 || C0 == 16))) &&
-      mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) {
+  if ((dtypes & MO_BF_MATH) && al16 && ub_views_ok(C0, C1) && mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) {
     UbConvArgs A;
     UdConvArgs& a = A.c;
     a.stats = stats;
@@ -338,8 +340,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
   const int Ci = C0 + C1;
   const bool in_al = (((uintptr_t)in0) & 15) == 0 && (istride0 & 3) == 0 && (C1 == 0 || ((((uintptr_t)in1) & 15) == 0 && (istride1 & 3) == 0));
   if ((dtypes & MO_BF_MATH) && (dtypes & MO_BF_DY) && in_al && (((uintptr_t)dy) & 15) == 0 && (dystride & 7) == 0 &&
-      Co <= 16 && (Wd % UB_TW) == 0 && (C1 == 0 || (C0 == C1 && (C0 == 4 || C0 == 8 || C0 == 16))) &&
-      mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) {
+      Co <= 16 && (Wd % UB_TW) == 0 && ub_views_ok(C0, C1) && mo_conv3x3_bf16_route(Ci, Co, n_img, H, Wd)) {
     // bf16 matrix pipe (unet_bf16.hpp): one slab row per (tile position, image range)
     const long tiles = H / UB_TH;                         // slab rows per image range: one per band of 16 image rows
     const long max_rows = ((long)Co * Ci * 9 <= UW_THIN_ROW) ? UW_THIN_SLABS : UD_MAX_SLABS;

@@ -126,7 +126,8 @@ def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev, out_bf=False
          (L.BF_MATH * int(math))
     # train mode: the BatchNorm statistics come out of the conv's own epilogue where the direct kernels run
     # (per-tile partial sums), else from one pass over the output
-    ntile = L.load().mo_conv3x3_stats_tiles2(sum(v.C for v in views), Co, n, H, W, dt) if training else 0
+    ntile = (L.load().mo_conv3x3_stats_tiles2(v0.C, views[1].C if len(views) > 1 else 0, Co, n, H, W, dt)
+             if training else 0)
     stats = _empty(n, ntile, Co, 2, dev=dev) if ntile else None
     L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, L.ptr(stats), dt, st)
     G = n // gs

@@ -133,7 +133,7 @@ def _conv3x3_bf16_matrix_pipe(L, lib, n, gs, C0, C1, Co, H, W, bf):
     x1d = dev(x1) if C1 else None
     args_in = (L.ptr(x0d), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1, L.ptr(x1d), C1, C1 * H * W, None, None, 0)
     dt = L.BF_MATH | ((L.BF_IN0 | L.BF_OUT) if bf else 0)
-    ntile = lib.mo_conv3x3_stats_tiles2(Ci, Co, n, H, W, dt)
+    ntile = lib.mo_conv3x3_stats_tiles2(C0, C1, Co, n, H, W, dt)
     assert ntile == (W // (64 if W % 64 == 0 else 32)) * (H // 16)
     stats = torch.full((n, ntile, Co, 2), float('nan'), device='cuda')
     Wd_ = dev(Wt)
@@ -338,3 +338,29 @@ def test_fc_three_way_bf16_split(L, P, K, N):
     L.call('mo_fc3_bwd_weight', L.ptr(dd), P, N, L.ptr(xd), K, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
     close(dW, dout.double().t() @ x.double(), tol=5e-5, what='fc3 weight gradient')
     close(db, dout.double().sum(0), tol=1e-5, what='fc3 bias gradient')
+
+
+@pytest.mark.parametrize('n,gs,C0,C1,Co,H,W', [(2, 1, 8, 0, 8, 24, 48), (2, 2, 40, 0, 8, 16, 64), (2, 1, 6, 2, 4, 16, 64)])
+def test_bf16_math_flag_falls_back_to_fp32_kernels(L, n, gs, C0, C1, Co, H, W):
+    """MO_BF_MATH on a shape the bf16 matrix-pipe kernels do not serve (image that does not tile into 16 x 64 pixels, more
+    than 32 input channels, a concat of unequal halves): the flag is ignored and the fp32 kernels answer with fp32
+    accuracy (1e-4), statistics rows as mo_conv3x3_stats_tiles2 announces them."""
+    lib = L.load()
+    G = n // gs
+    x0 = rand(1, (n, C0, H, W)); sc0, sh0 = rand(2, (G, C0)) * 0.3 + 1, rand(3, (G, C0)) * 0.3
+    ins = [act_view(x0, sc0, sh0, gs)]
+    x1 = rand(4, (n, C1, H, W)) if C1 else None
+    if C1:
+        ins.append(x1)
+    Ci = C0 + C1
+    Wt = rand(5, (Co, Ci, 3, 3)) / np.sqrt(9 * Ci)
+    ref = F.conv2d(torch.cat(ins, 1), Wt, None, padding=1)
+    out = torch.empty(n, Co, H, W, device='cuda')
+    ntile = lib.mo_conv3x3_stats_tiles2(C0, C1, Co, n, H, W, L.BF_MATH)
+    stats = torch.full((n, max(ntile, 1), Co, 2), float('nan'), device='cuda')
+    L.call('mo_conv3x3_fwd', L.ptr(dev(x0)), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1, L.ptr(dev(x1)) if C1 else None,
+           C1, C1 * H * W, None, None, 0, gs, L.ptr(dev(Wt)), Co, n, H, W, L.ptr(out), Co * H * W,
+           L.ptr(stats) if ntile else None, L.BF_MATH, L.stream())
+    close(out, ref, tol=1e-4, what='conv fwd (fp32 fallback under MO_BF_MATH)')
+    if ntile:
+        close(stats.cpu().double().sum(1)[..., 0], ref.double().sum((2, 3)), tol=1e-5, what='epilogue sum')

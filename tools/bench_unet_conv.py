@@ -68,7 +68,7 @@ for C0, bf0, C1, Co, S in LAYERS:
 
     def fwd(math):
         dt = L.BF_IN0 * bf0 | L.BF_OUT | (L.BF_MATH if math else 0)
-        nt = lib.mo_conv3x3_stats_tiles2(Ci, Co, n, S, S, dt)
+        nt = lib.mo_conv3x3_stats_tiles2(C0, C1, Co, n, S, S, dt)
         stats = torch.empty(n, nt, Co, 2, device=dev)
         return lambda: L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(W), Co, n, S, S, L.ptr(out), Co * S * S, L.ptr(stats), dt, st)
 
