@@ -274,6 +274,14 @@ def test_bf16_mode_trains_like_the_fp32_mode():
             tr.step()
             losses.append(float(loss))
         hist[mode] = losses
+    ev = {}
+    for mode in ('f32', 'bf16'):                                # eval mode (running statistics) through the same kernels,
+        m = _model().eval()                                     # from the seeded weights
+        m.act_dtype = mode
+        with torch.no_grad():
+            ev[mode] = m(x, tdim).float().cpu()
+    assert torch.isfinite(ev['bf16']).all()
+    assert float((ev['bf16'] - ev['f32']).abs().max()) <= 5e-2 * float(ev['f32'].abs().max())
     print('losses', hist)
     for a, b in zip(hist['f32'], hist['bf16']):
         assert abs(a - b) <= 1e-2 * abs(a), hist
