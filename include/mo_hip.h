@@ -216,7 +216,7 @@ int mo_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
 
 /* Activation storage ("bf16 mode" of BASELINE config 3): a `dtypes` argument says which of an entry point's activation
  * tensors are stored as bf16 instead of fp32 (the pointer types stay float*; strides count ELEMENTS).  Arithmetic is
- * fp32 either way.  bf16 storage exists on the direct / streaming kernels (3x3 convs with <= 32 output channels at
+ * fp32 unless MO_BF_MATH (below) is set as well.  bf16 storage exists on the direct / streaming kernels (3x3 convs with <= 32 output channels at
  * >= 32x32 pixels, the MFMA weight gradient at W % 64 == 0 and H % 8 == 0, thin 1x1 convs, activation kernels);
  * any other shape returns MO_EUNSUPPORTED when a flag is set. */
 #define MO_BF_IN0 1   /* first input view (mo_unet_act_bwd: y) */

@@ -176,7 +176,8 @@ class Modified_UNET(nn.Module):
         self.decoder = Decoder(self.horizon) if image_dimension == 128 else Decoder(self.horizon, image_dimension)
         self.expansion = Expansion(output_channels)
         # 'f32' (parity mode) | 'bf16' (BASELINE config 3): the raw conv outputs and their gradients at the large
-        # resolutions are stored as bf16 in HBM, arithmetic stays fp32 (unet_engine.bf_ok)
+        # resolutions are stored as bf16 in HBM (unet_engine.bf_ok), their 3x3 convs / gradients run on the bf16 matrix pipe
+        # with fp32 accumulation and the two large FC layers as 3 x bf16 split products; 'f32' is exact fp32
         self.act_dtype = 'f32'
 
     # ------------------------------------------------------------------ engine plumbing
