@@ -27,6 +27,10 @@ extern "C" {
 #define MO_ECOMM (-4)
 
 const char* mo_strerror(int code);
+/* Bumped whenever an existing entry point changes its argument list (a stale libmo_hip.so called through a newer ctypes
+ * table would silently misread its arguments): _lib.load() refuses a library whose mo_version() differs from
+ * _lib.ABI_VERSION.  3 = round 3 (mo_nchw_to_nbtc/mo_nbtc_to_nchw node_new, UNet `dtypes` words, ...). */
+#define MO_ABI_VERSION 3
 int mo_version(void);
 /* tuning switches for A/B measurements: "persist" (1: persistent skinny-K kernels; 0, default: one workgroup per tile) */
 int mo_set_option(const char* name, int value);

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmo_hip.so')
 
 _lib = None
+ABI_VERSION = 3          # == MO_ABI_VERSION of include/mo_hip.h; bump both when an entry point's arguments change
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
 
@@ -121,6 +122,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    have = lib.mo_version()
+    if have != ABI_VERSION:
+        raise RuntimeError(f'{LIB_PATH} is stale: it reports ABI version {have}, this package binds version '
+                           f'{ABI_VERSION}; rebuild it with `python -m multimodal_outage_amd.build --force`')
     _lib = lib
     return lib
 

@@ -1673,4 +1673,4 @@ extern "C" const char* mo_strerror(int code) {
     default: return "unknown error";
   }
 }
-extern "C" int mo_version(void) { return 1; }
+extern "C" int mo_version(void) { return MO_ABI_VERSION; }

@@ -7,16 +7,18 @@ from . import _lib as L
 
 
 def _to_nbtc(x):
+    if not x.is_cuda:
+        raise RuntimeError('nconv / linear / gcn run on the MI355X HIP path only (no CPU fallback); got a CPU tensor')
     B, C, N, T = x.shape
     x = x.contiguous().float()
     y = torch.empty((N * B * T, C), device=x.device, dtype=torch.float32)
-    L.call('mo_nchw_to_nbtc', L.ptr(x), L.ptr(y), B, C, N, T, L.stream())
+    L.call('mo_nchw_to_nbtc', L.ptr(x), L.ptr(y), B, C, N, T, None, L.stream())
     return y
 
 
 def _from_nbtc(y, B, C, N, T):
     x = torch.empty((B, C, N, T), device=y.device, dtype=torch.float32)
-    L.call('mo_nbtc_to_nchw', L.ptr(y), L.ptr(x), B, C, N, T, L.stream())
+    L.call('mo_nbtc_to_nchw', L.ptr(y), L.ptr(x), B, C, N, T, None, L.stream())
     return x
 
 
@@ -26,7 +28,7 @@ def nconv(x, A):
     B, C, N, T = x.shape
     xi = _to_nbtc(x)
     yi = torch.empty_like(xi)
-    A = A.contiguous().float()
+    A = A.to(x.device).contiguous().float()
     L.call('mo_adj_gemm', L.ptr(A), N, L.ptr(xi), L.ptr(yi), B * T * C, 0, L.stream())
     return _from_nbtc(yi, B, C, N, T)
 

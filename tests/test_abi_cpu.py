@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in mo_hip.h but not exported by libmo_hip.so'
     assert set(L.SIGNATURES) == set(names), set(L.SIGNATURES) ^ set(names)
-    assert lib.mo_version() >= 1
+    hdr = open(os.path.join(ROOT, 'include', 'mo_hip.h')).read()
+    assert lib.mo_version() == L.ABI_VERSION == int(re.search(r'#define\s+MO_ABI_VERSION\s+(\d+)', hdr).group(1))
     assert lib.mo_strerror(-1) == b'invalid argument'
     # argument validation happens before any device work: NULL pointers are rejected on a CPU-only host
     assert lib.mo_spmm_csr(None, None, None, 0, None, None, 0, 0, 0, 0, None) == -1
@@ -89,3 +90,43 @@ def test_aptinit_svd_initialisation():
     e2 = torch.mm(torch.diag(p[:10] ** 0.5), n[:, :10].t())
     assert torch.allclose(g.nodevec1, e1) and torch.allclose(g.nodevec2, e2)
     assert g.supports_len == 2 and list(g.state_dict())[:2] == ['nodevec1', 'nodevec2']
+
+
+def test_every_call_site_matches_the_ctypes_table():
+    """Walk every `L.call('mo_*', ...)` / `lib.mo_*(...)` of the package (and bench.py) with ast and check the number of
+    arguments against _lib.SIGNATURES -- round 2 shipped functional.py with 7 arguments for the 8-argument
+    mo_nchw_to_nbtc (an ABI change the call site did not follow; nothing ran it)."""
+    import ast
+    import multimodal_outage_amd._lib as L
+    files = [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]
+    for dirpath, _, fs in os.walk(os.path.join(ROOT, 'multimodal_outage_amd')):
+        files += [os.path.join(dirpath, f) for f in fs if f.endswith('.py')]
+    checked = 0
+    for path in files:
+        tree = ast.parse(open(path).read(), path)
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            f = node.func
+            name = nargs = None
+            if (isinstance(f, ast.Attribute) and f.attr == 'call' and node.args
+                    and isinstance(node.args[0], ast.Constant) and isinstance(node.args[0].value, str)
+                    and node.args[0].value.startswith('mo_')):
+                name, args = node.args[0].value, node.args[1:]
+            elif isinstance(f, ast.Attribute) and f.attr.startswith('mo_') and f.attr in L.SIGNATURES:
+                name, args = f.attr, node.args
+            if name is None:
+                continue
+            assert name in L.SIGNATURES, f'{path}:{node.lineno}: unknown entry point {name}'
+            want = len(L.SIGNATURES[name][1])
+            # `*view.args()` (6 values) and `*_NOVIEW` (6) are the two starred forms of the UNet engine; `*drop` is 3
+            n = 0
+            for a in args:
+                if isinstance(a, ast.Starred):
+                    src = ast.unparse(a.value)
+                    n += 6 if ('args()' in src or '_NOVIEW' in src or src in ('a1',)) else None
+                else:
+                    n += 1
+            assert n == want, f'{path}:{node.lineno}: {name} called with {n} arguments, the ABI takes {want}'
+            checked += 1
+    assert checked >= 120, checked

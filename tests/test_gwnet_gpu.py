@@ -594,3 +594,30 @@ def test_gwnet_batch_limit_of_32bit_row_offsets(c2_oracle):
         del y
         with pytest.raises(RuntimeError, match='unsupported configuration'):
             m(torch.cat([x, x2[:1]]))
+
+
+def test_helper_classes_nconv_linear_gcn_vs_oracle():
+    """graph_wavenet.py:60-98: the helper modules kept for API parity (nconv()(x, A), linear(c_in, c_out)(x),
+    gcn(...)(x, supports)) through their own forward()s on the HIP ops, against the oracle's restatement at (2,32,67,7)."""
+    from multimodal_outage_amd.models.graph_wavenet import nconv, linear, gcn
+    B, C, N, T = 2, 32, 67, 7
+    x = rand(900, (B, C, N, T))
+    A1 = torch.softmax(rand(901, (N, N)), dim=1)
+    A2 = torch.from_numpy(gwnet_ref.asym_adj(P.knn_graph(N, seed=4)))
+    y = nconv()(x.cuda(), A1.cuda())
+    assert_close(y, gwnet_ref.nconv(x, A1), 1e-5, 1e-4, 'nconv')
+    # a non-contiguous input (the reference's einsum accepts any strides)
+    xt = x.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
+    assert_close(nconv()(xt.cuda(), A1.cuda()), gwnet_ref.nconv(x, A1), 1e-5, 1e-4, 'nconv strided')
+    torch.manual_seed(5)
+    lin = linear(C, 48)
+    yl = lin.cuda()(x.cuda())
+    ref = F.conv2d(x, lin.mlp.weight.detach().cpu(), lin.mlp.bias.detach().cpu())
+    assert_close(yl, ref, 1e-5, 1e-4, 'linear')
+    g = gcn(C, 32, dropout=0.3, support_len=2).eval()
+    yg = g.cuda()(x.cuda(), [A1.cuda(), A2.cuda()])
+    ref = gwnet_ref.gcn(x, [A1, A2], g.mlp.mlp.weight.detach().cpu(), g.mlp.mlp.bias.detach().cpu(), 0.3, False)
+    assert yg.shape == (B, 32, N, T)
+    assert_close(yg, ref, 2e-5, 1e-4, 'gcn')
+    with pytest.raises(RuntimeError):
+        nconv()(x, A1)                    # CPU tensors: no fallback
