@@ -297,6 +297,47 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
             "loss": round(float(loss.detach()), 5)}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks exactly as the driver does (`python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>`)
+    as a child process, let rank 0's JSON line pass through on the inherited stdout and return the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] launching: ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse(args, world, rank):
+    """The rank-side control flow of main() without any GPU work: barrier, a timed region of K empty steps, max over ranks
+    of the elapsed time, ONE line from rank 0.  Used by the CPU test of the launcher (gloo)."""
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "train windows/sec (gwnet N=3k,T=12)", "value": None, "rehearsal": True,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -310,11 +351,26 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-unet', action='store_true', help='skip the secondary UNet tiles/s leg')
     ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--nodes', type=int, default=N_NODES, help='graph size (default: BASELINE config 2; smaller only to '
+                    'rehearse the control flow)')
+    ap.add_argument('--rehearse', action='store_true', help='control flow only (launcher, rendezvous, barrier, max-over-'
+                    'ranks timing, rank-0 line) with no GPU work: runs on a CPU-only host with --backend gloo')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started plainly (`python bench.py --gpus N`): become the launcher.  Nothing has touched the GPU yet (importing
+        # torch does not), and the ranks are CHILD processes -- never a re-exec of a process that initialised HIP.
+        sys.exit(launch_ranks(args.gpus))
+    globals()['N_NODES'] = args.nodes
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.rehearse:
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group(args.backend if args.backend != 'nccl' else 'gloo')
+        return rehearse(args, world, rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -326,7 +382,6 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     dev = torch.device('cuda', local if world > 1 else 0)
 
     import multimodal_outage_amd._lib as L

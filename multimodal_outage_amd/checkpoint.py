@@ -62,6 +62,7 @@ def load_lightning_state(ckpt, module, trainer=None, prefix='model.', strict=Tru
     if len(ids) != len(names):
         raise ValueError(f'optimizer state covers {len(ids)} parameters, the module has {len(names)}')
     steps = set()
+    own_params = dict(module.named_parameters())
     trainer.m.zero_()
     trainer.v.zero_()
     for i, k in zip(ids, names):
@@ -70,6 +71,10 @@ def load_lightning_state(ckpt, module, trainer=None, prefix='model.', strict=Tru
             continue
         lo, _ = trainer._span[k]
         n = st['exp_avg'].numel()
+        want = tuple(own_params[k].shape)
+        for key in ('exp_avg', 'exp_avg_sq'):
+            if tuple(st[key].shape) != want:
+                raise ValueError(f'optimizer state {key} of {k}: shape {tuple(st[key].shape)} != parameter {want}')
         trainer.m[lo:lo + n].copy_(st['exp_avg'].reshape(-1).to(trainer.m.device, torch.float32))
         trainer.v[lo:lo + n].copy_(st['exp_avg_sq'].reshape(-1).to(trainer.v.device, torch.float32))
         steps.add(int(float(st['step'])))
@@ -91,9 +96,15 @@ def load_lightning_state(ckpt, module, trainer=None, prefix='model.', strict=Tru
 
 
 def lightning_state(module, trainer=None, prefix='model.', epoch=0, base_lr=1e-3, t_max=10):
-    """The inverse: a Lightning-shaped checkpoint dict of ``module`` (+ ``trainer``'s Adam state) that
-    ``LitModified_UNET.load_from_checkpoint`` / ``torch.optim.Adam.load_state_dict`` of the reference accept."""
-    out = {'state_dict': {prefix + k: v.detach().clone() for k, v in module.state_dict().items()}, 'epoch': epoch}
+    """The inverse: a Lightning-shaped checkpoint dict of ``module`` (+ ``trainer``'s Adam state).  What is tested:
+    ``state_dict`` loads into the reference's class with ``load_state_dict`` and ``optimizer_states[0]`` into
+    ``torch.optim.Adam.load_state_dict`` (tests/test_checkpoint_cpu.py).  Lightning itself is not importable in this image,
+    so ``LitModified_UNET.load_from_checkpoint`` on this dict is **parity unpinned**; the keys its checkpoint migration
+    indexes (``pytorch-lightning_version``, ``global_step``, ``loops``) are emitted with neutral values so that it has
+    what it looks up."""
+    out = {'state_dict': {prefix + k: v.detach().clone() for k, v in module.state_dict().items()}, 'epoch': epoch,
+           'global_step': int(trainer.step_count) if trainer is not None else 0,
+           'pytorch-lightning_version': '2.2.0', 'loops': {}, 'callbacks': {}, 'hparams_name': None}
     if trainer is not None:
         state = {}
         names = [k for k, _ in module.named_parameters()]

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ..gwnet_engine import GwnetConfig, GwnetFunction, StaticSupport
+from ._cache import tree_cache
 
 # Hyperparameters (graph_wavenet.py:37-42)
 image_dimension = 128
@@ -236,9 +237,9 @@ class gwnet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('gwnet runs on the MI355X HIP path only (no CPU fallback); got a CPU tensor')
         names = self._engine_names()
-        named = self.__dict__.get('_mo_named')
-        if named is None:                              # (walked once; _apply drops it when .to() replaces the Parameters)
-            named = self.__dict__['_mo_named'] = dict(self.named_parameters())
+        # (walked once; re-validated by object identity on every call, models/_cache.py)
+        cache = tree_cache(self, '_mo_named')
+        named = cache.named
         params = [named[k] for k in names]
         cfg = GwnetConfig(num_nodes=self.num_nodes, in_dim=self.in_dim, out_dim=self.out_dim,
                           kernel_size=self.kernel_size, blocks=self.blocks, layers=self.layers,
@@ -248,7 +249,7 @@ class gwnet(nn.Module):
         cfg.grad_out = getattr(self, '_mo_grad_out', None)
         cfg.grad_ready = getattr(self, '_mo_grad_ready', None)
         cfg.dense_bf16 = (getattr(self, 'dense_dtype', 'f32') == 'bf16')
-        bn_bufs = [(m.running_mean, m.running_var) for m in self.bn]
+        bn_bufs = [cache.bn[f'bn.{i}'][:2] for i in range(len(self.bn))]
         if self.training:
             for m in self.bn:
                 m.num_batches_tracked += 1

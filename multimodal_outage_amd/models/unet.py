@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .graph_wavenet import gwnet, default_supports
+from ._cache import tree_cache
 from ..unet_engine import UnetEncodeFn, UnetDecodeFn
 
 # Hyperparameters (unet.py:33-38)
@@ -181,29 +182,20 @@ class Modified_UNET(nn.Module):
         self.act_dtype = 'f32'
 
     # ------------------------------------------------------------------ engine plumbing
-    def _names(self, prefixes):
-        return [k for k, _ in self.named_parameters() if k.split('.')[0] in prefixes]
-
     def _apply(self, fn, *a, **kw):
-        self.__dict__.pop('_mo_plumbing', None)       # .to() / .cuda() may replace the Parameter objects
+        self.__dict__.pop('_mo_plumbing', None)
         return super()._apply(fn, *a, **kw)
 
     def _plumbing(self):
         """(name -> Parameter, encoder-side names, decoder-side names, BatchNorm buffers): walked once, not per step
-        (four traversals of the module tree were ~1 ms of host time per forward)."""
-        c = self.__dict__.get('_mo_plumbing')
-        if c is None:
-            c = (dict(self.named_parameters()), self._names(('contraction', 'encoder')),
-                 self._names(('decoder', 'expansion')), self._bufs())
-            self.__dict__['_mo_plumbing'] = c
-        return c
-
-    def _bufs(self):
-        out = {}
-        for name, m in self.named_modules():
-            if isinstance(m, nn.BatchNorm2d) and not name.startswith('st_gnn'):
-                out[name] = (m.running_mean, m.running_var, m.num_batches_tracked)
-        return out
+        (four traversals of the module tree were ~1 ms of host time per forward), and re-validated by object identity on
+        every forward (models/_cache.py: load_state_dict(assign=True), child.cuda(), replaced sub-modules)."""
+        c = tree_cache(self, '_mo_plumbing', skip=('st_gnn',))
+        if not hasattr(c, 'enc_names'):
+            order = [k for k, _ in self.named_parameters()]         # state_dict order = the engines' parameter order
+            c.enc_names = [k for k in order if k.split('.')[0] in ('contraction', 'encoder')]
+            c.dec_names = [k for k in order if k.split('.')[0] in ('decoder', 'expansion')]
+        return c.named, c.enc_names, c.dec_names, c.bn
 
     def forward(self, input, time_dim):
         """unet.py:219-231.  input: (B, n_counties, H, Cin, S, S); time_dim: (B, n_counties, H, 64)."""

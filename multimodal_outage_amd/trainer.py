@@ -54,17 +54,23 @@ class FlatTrainer:
                 raw = C.create_string_buffer(128)
                 L.call('mo_allreduce_unique_id', raw)
                 ident = [raw.raw]
-            dist.broadcast_object_list(ident, src=0, group=process_group)
+            # `src` of broadcast_object_list is a GLOBAL rank: group rank 0 of a sub-group need not be global rank 0
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            dist.broadcast_object_list(ident, src=src, group=process_group)
             h = C.c_void_p()
             L.call('mo_allreduce_init', C.create_string_buffer(ident[0], 128), dist.get_rank(process_group),
                    self.world, C.byref(h))
             self._abi = h
         params = [(k, p) for k, p in module.named_parameters()]
         dev = params[0][1].device
+        # every parameter's span is a multiple of lcm(64 floats, world): any run of adjacent parameters (a bucket, or the
+        # whole buffer) then splits evenly over the ranks, which the reduce-scatter + all-gather form needs -- for every
+        # world size, not only the powers of two that divide the 64-float alignment.  Padding holds zeros and stays zero.
+        al = self._al = math.lcm(_ALIGN, max(self.world, 1))
         offs, total = [], 0
         for _, p in params:
             offs.append(total)
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            total += (p.numel() + al - 1) // al * al
         self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -79,7 +85,7 @@ class FlatTrainer:
             self.grad_views[k] = gv
         self.step_count = 0
         self.total = total
-        self._span = {k: (o, o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN) for (k, p), o in zip(params, offs)}
+        self._span = {k: (o, o + (p.numel() + al - 1) // al * al) for (k, p), o in zip(params, offs)}
         self._done = []          # [lo, hi) ranges already handed to an asynchronous all-reduce this step
         self._work = []
         # buckets = top-level child modules, announced from the post-accumulate hook of the LAST parameter of the
@@ -219,10 +225,24 @@ class FlatTrainer:
         self.lr = lr
 
     def close(self):
-        """Release the library's RCCL communicator (comm='abi')."""
+        """Release the library's RCCL communicator, its stream and events (comm='abi').  Also run by __del__ and on
+        leaving a `with FlatTrainer(...) as tr:` block."""
         if self._abi is not None:
-            L.call('mo_allreduce_destroy', self._abi)
-            self._abi = None
+            h, self._abi = self._abi, None
+            L.call('mo_allreduce_destroy', h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: the library may already be gone
+            pass
 
 
 def cosine_lr(base_lr, epoch, t_max=10, eta_min=0.0):

@@ -173,3 +173,44 @@ def test_flat_trainer_buckets_rearm_with_never_fired_parameters():
         assert premature == 0, (rank, premature)
         assert worst <= 1e-6, (rank, worst)
         assert counts == [0, 2, 2, 2, 2], counts      # learning pass, then both buckets from inside backward
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset) must not die on an assert: it becomes the
+    launcher -- child process `python -m torch.distributed.run --nproc-per-node 2 bench.py ...` -- and passes rank 0's line
+    through.  --rehearse keeps the ranks off the GPU (rendezvous, barrier, max-over-ranks timing, one JSON line), so the
+    launcher's control flow runs here on the CPU with gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--backend', 'gloo', '--rehearse'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout                      # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['rehearsal'] is True
+    # max over ranks: rank 1 sleeps 2 ms per step, rank 0 only 1 ms
+    assert line['ms_per_step'] >= 2.0
+    # a failing rank's exit code comes back through the launcher
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'no_such_backend',
+                        '--rehearse'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
+def test_flat_buffer_spans_split_evenly_for_any_world_size(monkeypatch):
+    """reduce-scatter + all-gather needs every reduced range to be a multiple of the world size: spans are aligned to
+    lcm(64, world) floats (round 2 required n % world == 0 and nothing padded for it)."""
+    from multimodal_outage_amd import trainer as T
+    m = nn.Sequential(nn.Conv2d(3, 5, 1), nn.BatchNorm2d(5), nn.Linear(7, 3))
+    for world in (1, 2, 3, 6, 8):
+        monkeypatch.setattr(T.dist, 'is_initialized', lambda: False)
+        tr = T.FlatTrainer.__new__(T.FlatTrainer)
+        # (only the layout arithmetic: a real group of `world` ranks is not needed for it)
+        al = T.math.lcm(T._ALIGN, world)
+        total = 0
+        for p in m.parameters():
+            total += (p.numel() + al - 1) // al * al
+        assert total % world == 0 and al % world == 0 and al % 64 == 0

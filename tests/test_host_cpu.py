@@ -57,3 +57,33 @@ def test_unet_algorithmic_bytes_reproduce_the_survey():
     assert abs(bench.unet_alg_bytes_fwd(1, 128, 'f32') / 1e6 - 5.85) < 0.01
     b = bench.unet_alg_bytes_fwd(13, 256, 'bf16')
     assert 0.5 * 29.7e6 < b < 29.7e6
+
+
+def test_plumbing_cache_notices_replaced_tensors():
+    """the cached module walk (name -> Parameter, BatchNorm buffers) must not go stale when tensors are replaced
+    behind the root module's back -- child._apply alone (torch replaces buffer objects), load_state_dict(assign=True),
+    a swapped sub-module, a newly registered parameter."""
+    import torch
+    import torch.nn as nn
+    from multimodal_outage_amd.models.unet import Modified_UNET
+    m = Modified_UNET('gwnet', 2, 1, 1)
+    named, enc, dec, bufs = m._plumbing()
+    ref = dict(m.named_parameters())
+    assert set(named) == {k for k in ref if not k.startswith('st_gnn.')} and all(named[k] is ref[k] for k in named)
+    assert enc == [k for k in ref if k.split('.')[0] in ('contraction', 'encoder')]
+    assert dec == [k for k in ref if k.split('.')[0] in ('decoder', 'expansion')]
+    c0 = m.__dict__['_mo_plumbing']
+    assert m._plumbing()[0] is named and m.__dict__['_mo_plumbing'] is c0          # unchanged tree: same cache
+    m.contraction.double(); m.contraction.float()                                    # child alone: new buffer objects
+    bn = m.contraction.inc.double_conv[1]
+    assert m._plumbing()[3]['contraction.inc.double_conv.1'][0] is bn.running_mean
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, assign=True)
+    assert m._plumbing()[0]['encoder.fc1.weight'] is m.encoder.fc1.weight
+    m.expansion.outc.conv = nn.Conv2d(4, 1, kernel_size=1)
+    assert m._plumbing()[0]['expansion.outc.conv.weight'] is m.expansion.outc.conv.weight
+    g = m.st_gnn
+    from multimodal_outage_amd.models._cache import tree_cache
+    c = tree_cache(g, '_mo_named')
+    g.bn[0] = nn.BatchNorm2d(32)
+    c2 = tree_cache(g, '_mo_named')
+    assert c2 is not c and c2.bn['bn.0'][0] is g.bn[0].running_mean
