@@ -219,21 +219,24 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
     """Secondary metric of BASELINE.json ("+ UNet tiles/sec"): Modified_UNET training step (forward + MSE/metrics +
     backward + all-reduce + Adam) on synthetic (B,67,H,13,256,256) GOES-style tiles (config 3), batch-sharded
     like the gwnet leg.  Returns the object printed under "unet"."""
-    from multimodal_outage_amd.models.unet import Modified_UNET
-    from multimodal_outage_amd.lit import mse_and_metrics
+    from multimodal_outage_amd.lit import LitModified_UNET
     from multimodal_outage_amd.trainer import FlatTrainer
     torch.manual_seed(42)
-    m = Modified_UNET('gwnet', horizon, input_channels=cin, output_channels=cin, image_dimension=size).to(dev).train()
+    # the lit.py surface itself: LitModified_UNET(st_gnn, horizon, device).training_step(batch) (lit.py:18-43), the batch in
+    # the DataLoader's layout (x, y: (B, H, 67, C, S, S); x_time: (B, 67, H, 64), utils.py:101-105) -- the (0,2,1,3,4,5)
+    # permute of lit.py:31 is inside the timed step (folded into image offsets, no copy)
+    lit = LitModified_UNET('gwnet', horizon, dev, input_channels=cin, output_channels=cin, image_dimension=size)
+    m = lit.model.train()
     m.act_dtype = act_dtype      # BASELINE config 3 names bf16 (storage + matrix-pipe arithmetic, DESIGN 3.5)
     tr = FlatTrainer(m).attach()
     g = torch.Generator().manual_seed(2000 + int(os.environ.get('RANK', '0')))
-    x = torch.randn(batch, 67, horizon, cin, size, size, generator=g).to(dev)
-    y = torch.randn(batch, 67, horizon, cin, size, size, generator=g).to(dev)
+    x = torch.randn(batch, horizon, 67, cin, size, size, generator=g).to(dev)
+    y = torch.randn(batch, horizon, 67, cin, size, size, generator=g).to(dev)
     td = torch.randn(batch, 67, horizon, 64, generator=g).to(dev)
 
     def step():
         tr.zero_grad()
-        loss, _, _, _ = mse_and_metrics(m(x, td), y)
+        loss = lit.training_step((x, y, td))
         loss.backward()
         tr.allreduce()
         tr.step()

@@ -30,7 +30,7 @@ const char* mo_strerror(int code);
 /* Bumped whenever an existing entry point changes its argument list (a stale libmo_hip.so called through a newer ctypes
  * table would silently misread its arguments): _lib.load() refuses a library whose mo_version() differs from
  * _lib.ABI_VERSION.  3 = round 3 (mo_nchw_to_nbtc/mo_nbtc_to_nchw node_new, UNet `dtypes` words, ...). */
-#define MO_ABI_VERSION 3
+#define MO_ABI_VERSION 4
 int mo_version(void);
 /* tuning switches for A/B measurements: "persist" (1: persistent skinny-K kernels; 0, default: one workgroup per tile) */
 int mo_set_option(const char* name, int value);
@@ -243,7 +243,10 @@ int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, co
                    int gsize, const float* W, int Co, long n_img, int H, int Wd, float* out, long ostride,
                    float* stats /* optional [n_img][tiles][Co][2] per-tile (sum, sumsq) of out, tiles =
                    mo_conv3x3_stats_tiles(): the BatchNorm statistics come out of the conv's epilogue; NULL: none */,
-                   int dtypes /* MO_BF_IN0 | MO_BF_IN1 | MO_BF_OUT */, void* stream);
+                   int dtypes /* MO_BF_IN0 | MO_BF_IN1 | MO_BF_OUT */,
+                   const long long* in0_off /* NULL, or per-image ELEMENT offsets of the first view: image img lies at
+                   in0 + in0_off[img] instead of in0 + img * istride0 -- the network input as the permuted batch view of
+                   lit.py:31, read in place (direct / matrix-pipe kernels only, else MO_EUNSUPPORTED) */, void* stream);
 /* per-image statistics rows mo_conv3x3_fwd writes for this shape (0: none -- run mo_nchw_stats on the output) */
 int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
 /* ... when the call carries `dtypes` and the two views (MO_BF_MATH routes to the bf16 matrix-pipe kernel, whose tiles are 16 x 64) */
@@ -258,7 +261,8 @@ int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, const float* i
                           const float* sc0, const float* sh0, int relu0, const float* in1, int C1,
                           long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
                           long n_img, int H, int Wd, float* dW, float* ws,
-                          int dtypes /* MO_BF_DY | MO_BF_IN0 | MO_BF_IN1 */, void* stream);
+                          int dtypes /* MO_BF_DY | MO_BF_IN0 | MO_BF_IN1 */,
+                          const long long* in0_off /* as mo_conv3x3_fwd */, void* stream);
 /* OutConv (unet.py:86-92): 1x1 conv with bias on an activated NCHW view */
 int mo_nchw_conv1x1_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                         int gsize, const float* W, const float* b, int Co, long n_img, int HW, float* out,
@@ -270,6 +274,21 @@ int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int Co, const f
                                int Ci, const float* sc, const float* sh, int relu, int gsize, long n_img,
                                int HW, float* dW, float* db, float* ws, int dtypes /* MO_BF_DY | MO_BF_IN0 */,
                                void* stream);
+/* OutConv + loss + OutConv backward in one pass -- the tail of training_step (lit.py:32-38 on unet.py:86-92: yhat =
+ * OutConv(act(in)); loss = MSE(yhat, y); MAE / MAPE / RMSE).  yhat is consumed by the loss only, so it is formed in registers
+ * (written to `yhat` only when that is not NULL); the pass also leaves da = d loss / d act(in) (Ci planes per image,
+ * MO_BF_OUT: bf16) and the slab rows of dW / db in `ws`, all for an upstream gradient d loss = 1 (consumers scale:
+ * mo_unet_act_bwd's out_scale, mo_outc_loss_bwd's scale).  target: Co planes of HW floats per image at
+ * target + (target_off ? target_off[img] : img * Co * HW)  (lit.py:31 hands a permuted view of the batch).
+ * out4 = {mse, mae, mape, rmse} (MAPE eps 1.17e-6, as torchmetrics).  Ci <= 4, Co <= 16. */
+long mo_outc_loss_ws_floats(long n_img, int HW, int Ci, int Co);
+int mo_outc_loss_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu, int gsize,
+                     const float* W, const float* b, int Co, const float* target, const long long* target_off,
+                     long n_img, int HW, float* yhat, float* da, long dastride, float* ws, float* out4,
+                     int dtypes /* MO_BF_IN0 | MO_BF_OUT (da) */, void* stream);
+/* dW (Co,Ci), db (Co) = (sum of ws's slab rows) * *scale  (scale: device scalar, the upstream gradient of the loss; NULL = 1) */
+int mo_outc_loss_bwd(const float* ws, long n_img, int HW, int Ci, int Co, const float* scale, float* dW, float* db,
+                     void* stream);
 /* Up.up (unet.py:71): ConvTranspose2d(Ci, Co, k=2, s=2) with bias; W (Ci, Co, 2, 2); H,Wd = input size */
 int mo_convt2x2_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                     int gsize, const float* W, const float* b, int Co, long n_img, int H, int Wd, float* out,
@@ -304,7 +323,9 @@ int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, int H, int 
                     const float* gamma, const float* mean, const float* rstd, const float* sc,
                     const float* sh, const float* da, long dastride, const float* dp, long dpstride,
                     float* dy, long dystride, float* dgamma, float* dbeta, float* ws,
-                    int dtypes /* MO_BF_IN0 (y) | MO_BF_IN1 (da) | MO_BF_DP | MO_BF_OUT (dy) */, void* stream);
+                    int dtypes /* MO_BF_IN0 (y) | MO_BF_IN1 (da) | MO_BF_DP | MO_BF_OUT (dy) */,
+                    const float* out_scale /* device scalar or NULL: dy, dgamma, dbeta are multiplied by it -- the upstream
+                    gradient of the loss when da comes from mo_outc_loss_fwd, which forms it for d loss = 1 */, void* stream);
 /* out[c] = sum over images and pixels (bias gradients); ws: n_img*C*2 floats */
 int mo_nchw_channel_sum(const float* x, long istride, int C, long n_img, int HW, float* out, float* ws,
                         void* stream);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmo_hip.so')
 
 _lib = None
-ABI_VERSION = 3          # == MO_ABI_VERSION of include/mo_hip.h; bump both when an entry point's arguments change
+ABI_VERSION = 4          # == MO_ABI_VERSION of include/mo_hip.h; bump both when an entry point's arguments change
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
 
@@ -66,14 +66,14 @@ SIGNATURES = {
     'mo_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, vp]),
     # ---- UNet
     'mo_conv3x3_fwd': (i32, [vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32, vp, i32, i64, i32, i32,
-                             vp, i64, vp, i32, vp]),
+                             vp, i64, vp, i32, vp, vp]),
     'mo_conv3x3_stats_tiles': (i32, [i32, i64, i32, i32]),
     'mo_conv3x3_stats_tiles2': (i32, [i32, i32, i32, i64, i32, i32, i32]),
     'mo_conv3x3_bf16_route': (i32, [i32, i32, i64, i32, i32]),
     'mo_conv3x3_flip_weights': (i32, [vp, i32, i32, vp, vp]),
     'mo_unet_wgrad_ws_floats': (i64, [i32, i32, i64]),
     'mo_conv3x3_bwd_weight': (i32, [vp, i64, i32, vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32,
-                                    i64, i32, i32, vp, vp, i32, vp]),
+                                    i64, i32, i32, vp, vp, i32, vp, vp]),
     'mo_nchw_conv1x1_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, vp, i64, i32, vp]),
     'mo_nchw_conv1x1_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, vp, i64, i32, vp]),
     'mo_nchw_conv1x1_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
@@ -92,7 +92,11 @@ SIGNATURES = {
     'mo_unet_act': (i32, [vp, i64, i32, i64, i32, i32, vp, vp, i32, i32, vp, i64, i32, vp]),
     'mo_unet_act_bwd_ws_floats': (i64, [i64, i32]),
     'mo_unet_act_bwd': (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64,
-                              vp, vp, vp, i32, vp]),
+                              vp, vp, vp, i32, vp, vp]),
+    'mo_outc_loss_ws_floats': (i64, [i64, i32, i32, i32]),
+    'mo_outc_loss_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp, vp, i64, vp, vp, i32,
+                               vp]),
+    'mo_outc_loss_bwd': (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp]),
     'mo_nchw_channel_sum': (i32, [vp, i64, i32, i64, i32, vp, vp, vp]),
     'mo_maxpool2_bwd': (i32, [vp, i64, i32, i64, i32, i32, vp, i64, vp, i64, vp]),
     'mo_raster_prepare': (i32, [vp, i64, i32, i32, f32, f32, f32, vp, i32, i32, vp]),

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     constexpr int SL = decltype(slotc)::value;
     constexpr int es = BF ? 2 : 4;
     const __amdgpu_buffer_rsrc_t rs = sec ? ub_rsrc(reinterpret_cast<const char*>(a.in1) + img * a.is1 * es, (long)a.C1 * HW * es)
-                                          : ub_rsrc(reinterpret_cast<const char*>(a.in0) + img * a.is0 * es, (long)a.C0 * HW * es);
+                                          : ub_rsrc(reinterpret_cast<const char*>(a.in0) + ud_base0(a, img) * es, (long)a.C0 * HW * es);
     const int pb = HW * es;                               // channels past the view's count fall out of the descriptor's range
 #pragma unroll
     for (int tl = 0; tl < NTS; ++tl) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
     constexpr bool BF = decltype(bfc)::value;
     constexpr int es = BF ? 2 : 4;
     const __amdgpu_buffer_rsrc_t rs = sec ? ub_rsrc(reinterpret_cast<const char*>(a.in1) + img * a.is1 * es, (long)a.C1 * HW * es)
-                                          : ub_rsrc(reinterpret_cast<const char*>(a.in0) + img * a.is0 * es, (long)a.C0 * HW * es);
+                                          : ub_rsrc(reinterpret_cast<const char*>(a.in0) + ud_base0(a, img) * es, (long)a.C0 * HW * es);
 #pragma unroll
     for (int cp = 0; cp < NCP; ++cp)
 #pragma unroll

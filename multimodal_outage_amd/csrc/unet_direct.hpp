@@ -42,7 +42,10 @@ struct UdConvArgs {
   int Co, H, Wd, gsize;
   float* stats;            // optional [img][tile][Co][2]: per-tile (sum, sum of squares) of the raw outputs
   int bf0, bf1, bfo;       // storage of in0 / in1 / out: 0 fp32, 1 bf16 (strides are in ELEMENTS either way)
+  const long* off0 = nullptr;   // optional per-image ELEMENT offsets of in0 (image img at in0 + off0[img] instead of
+                                // in0 + img * is0): the network input as the permuted batch view of lit.py:31, no copy
 };
+template <class A> __device__ __forceinline__ long ud_base0(const A& a, long img) { return a.off0 ? a.off0[img] : img * a.is0; }
 
 // activated value of channel c (of the concat) at (y, x) of image img; zero outside the image
 __device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, long grp, int c, int y, int x) {
@@ -50,8 +53,8 @@ __device__ __forceinline__ float ud_act(const UdConvArgs& a, long img, long grp,
   const bool first = c < a.C0;
   const int cc = first ? c : c - a.C0;
   const float* base = first ? a.in0 : a.in1;
-  const long is = first ? a.is0 : a.is1;
-  float v = ua_ld1(base, img * is + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
+  const long ib = first ? ud_base0(a, img) : img * a.is1;
+  float v = ua_ld1(base, ib + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
   const float* sc = first ? a.sc0 : a.sc1;
   if (sc) {
     const float* sh = first ? a.sh0 : a.sh1;
@@ -81,8 +84,8 @@ __device__ __forceinline__ void ud_stage_halo(float* tile /* [nc][TH+2][LDT] */,
       const bool first = cg < a.C0;
       const int cc = first ? cg : cg - a.C0;
       const float* base = first ? a.in0 : a.in1;
-      const long is = first ? a.is0 : a.is1;
-      v = ua_ld4(base, img * is + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
+      const long ib = first ? ud_base0(a, img) : img * a.is1;
+      v = ua_ld4(base, ib + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
       const float* sc = first ? a.sc0 : a.sc1;
       if (sc) {
         const float* sh = first ? a.sh0 : a.sh1;
@@ -198,6 +201,7 @@ struct UdWgradArgs {
   int Co, H, Wd, gsize;
   long n_img; int img_per_wg, n_cichunk;
   int bfd, bf0, bf1;       // storage of dy / in0 / in1 (0 fp32, 1 bf16); the VALU kernel below takes fp32 only
+  const long* off0 = nullptr;   // optional per-image element offsets of in0 (as UdConvArgs::off0)
 };
 
 template <int TH, int TW>
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void ud_wgrad3x3_kernel(UdWgradArgs a) {
   const int Ci = a.C0 + a.C1;
   // the conv arguments of ud_act
   UdConvArgs ca;
-  ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
+  ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0; ca.off0 = a.off0;
   ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
   ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize; ca.stats = nullptr;
   ca.bf0 = a.bf0; ca.bf1 = a.bf1; ca.bfo = 0;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
   const int ci0 = blockIdx.z * UW_CIC;
   const int cic = min(UW_CIC, Ci - ci0);
   UdConvArgs ca;
-  ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0;
+  ca.in0 = a.in0; ca.sc0 = a.sc0; ca.sh0 = a.sh0; ca.is0 = a.is0; ca.C0 = a.C0; ca.relu0 = a.relu0; ca.off0 = a.off0;
   ca.in1 = a.in1; ca.sc1 = a.sc1; ca.sh1 = a.sh1; ca.is1 = a.is1; ca.C1 = a.C1; ca.relu1 = a.relu1;
   ca.W = nullptr; ca.out = nullptr; ca.os = 0; ca.Co = a.Co; ca.H = a.H; ca.Wd = a.Wd; ca.gsize = a.gsize; ca.stats = nullptr;
   ca.bf0 = a.bf0; ca.bf1 = a.bf1; ca.bfo = 0;
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
         const bool first = cg < a.C0;
         const int cc = first ? cg : cg - a.C0;
         const float* base = first ? a.in0 : a.in1;
-        const long is = first ? a.is0 : a.is1;
-        v = ua_ld4(base, img * is + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
+        const long ib = first ? ud_base0(a, img) : img * a.is1;
+        v = ua_ld4(base, ib + ((long)cc * a.H + y) * a.Wd + x, first ? a.bf0 : a.bf1);
         const float* sc = first ? a.sc0 : a.sc1;
         if (sc) {
           const float* sh = first ? a.sh0 : a.sh1;

@@ -212,7 +212,7 @@ extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd) {
 extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const float* sc0, const float* sh0, int relu0,
                               const float* in1, int C1, long istride1, const float* sc1, const float* sh1, int relu1,
                               int gsize, const float* W, int Co, long n_img, int H, int Wd, float* out, long ostride,
-                              float* stats, int dtypes, void* stream) {
+                              float* stats, int dtypes, const long long* in0_off, void* stream) {
   MO_CHECK_ARG(in0 && W && out && C0 > 0 && C1 >= 0 && Co > 0 && n_img > 0 && H > 0 && Wd > 0 && (Wd % 4) == 0);
   MO_CHECK_ARG(C1 == 0 || in1);
   const long P = n_img * H * Wd;
@@ -230,6 +230,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
     a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
     a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+    a.off0 = reinterpret_cast<const long*>(in0_off);
     A.flip = (dtypes & MO_W_FLIP) != 0; A.n_img = (int)n_img;
     const long bands = H / UB_TH;                         // a workgroup = one band of 16 rows x a range of images
     long ipw = (bands * n_img) / 1024;                    // (weights / staging pattern are set up once per workgroup)
@@ -261,6 +262,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
     a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
     a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+    a.off0 = reinterpret_cast<const long*>(in0_off);
     hipStream_t st = ST(stream);
     dim3 grid(Wd / uxw, H / (256 / uxw), (unsigned)n_img);
 #define UX_LAUNCH(MB) do { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32>), grid, dim3(256), 0, st, a); \
@@ -276,6 +278,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     a.in0 = in0; a.sc0 = sc0; a.sh0 = sh0; a.is0 = istride0; a.C0 = C0; a.relu0 = relu0;
     a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
     a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
+    a.off0 = reinterpret_cast<const long*>(in0_off);
     hipStream_t st = ST(stream);
     const bool wide = Wd >= 64;
     dim3 grid(mo_cdiv(Wd, wide ? 64 : 32), mo_cdiv(H, wide ? 16 : 32), (unsigned)n_img);
@@ -285,7 +288,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
 #undef UD_LAUNCH
     return mo_launch_status();
   }
-  if (dtypes) return MO_EUNSUPPORTED;            // bf16 storage exists on the direct kernels only
+  if (dtypes || in0_off) return MO_EUNSUPPORTED;   // bf16 storage / per-image offsets exist on the direct kernels only
   MO_CHECK_ARG(!stats);                          // (mo_conv3x3_stats_tiles() == 0 for every shape that gets here ...
   MoOperand A = uplain(W, Ci * 9, Co, Ci * 9);   // XROWS: rows = m = co, cols = k = (ci,tap)
   MoOperand B = im2col_operand(in0, C0, istride0, sc0, sh0, relu0, in1, C1, istride1, sc1, sh1, relu1, P);
@@ -333,7 +336,8 @@ static void uw_launch(const UdWgradArgs& a, int Ci, int Co, dim3 grid, hipStream
 extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, const float* in0, int C0, long istride0,
                                      const float* sc0, const float* sh0, int relu0, const float* in1, int C1,
                                      long istride1, const float* sc1, const float* sh1, int relu1, int gsize,
-                                     long n_img, int H, int Wd, float* dW, float* ws, int dtypes, void* stream) {
+                                     long n_img, int H, int Wd, float* dW, float* ws, int dtypes,
+                                     const long long* in0_off, void* stream) {
   MO_CHECK_ARG(dy && in0 && dW && ws && C0 > 0 && C1 >= 0 && Co > 0 && n_img > 0 && (Wd % 4) == 0);
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31));
@@ -355,6 +359,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
       a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
       a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = 1;
+      a.off0 = reinterpret_cast<const long*>(in0_off);
       a.bfd = 1; a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0;
       dim3 grid((unsigned)tiles, (unsigned)nchunk);
       hipStream_t st = ST(stream);
@@ -388,6 +393,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
       a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
       a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UW_CIC);
+      a.off0 = reinterpret_cast<const long*>(in0_off);
       a.bfd = (dtypes & MO_BF_DY) != 0; a.bf0 = (dtypes & MO_BF_IN0) != 0; a.bf1 = (dtypes & MO_BF_IN1) != 0;
       dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)a.n_cichunk);
       hipStream_t st = ST(stream);
@@ -416,6 +422,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       a.in1 = in1; a.sc1 = sc1; a.sh1 = sh1; a.is1 = istride1; a.C1 = C1; a.relu1 = relu1;
       a.slab = ws; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
       a.n_img = n_img; a.img_per_wg = (int)ipw; a.n_cichunk = mo_cdiv(Ci, UD_WI);
+      a.off0 = reinterpret_cast<const long*>(in0_off);
       a.bfd = a.bf0 = a.bf1 = 0;
       dim3 grid((unsigned)tiles, (unsigned)nchunk, (unsigned)(a.n_cichunk * mo_cdiv(Co, UD_WC)));
       hipStream_t st = ST(stream);
@@ -426,6 +433,7 @@ extern "C" int mo_conv3x3_bwd_weight(const float* dy, long dystride, int Co, con
       return mo_launch_status();
     }
   }
+  if (in0_off) return MO_EUNSUPPORTED;           // per-image offsets exist on the direct / matrix-pipe kernels only
   MoGeom G = geom(H, Wd, gsize, C0, C1);
   MoOperand A; uop(A, Co, P); useg(A.seg[0], dy, dystride, nullptr, nullptr, 0);     // NCHW XROWS rows = co, cols = p
   MoGeom Ga = G; Ga.C0 = Co;
@@ -528,6 +536,54 @@ extern "C" int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int 
   MoOperand B; uop(B, Ci, P); useg(B.seg[0], in, istride, sc, sh, relu);
   MoGeom G = geom(1, HW, gsize, Ci, 0);
   return uwgrad<MO_SRC_NCHW, MO_SRC_NCHW>(A, B, G, Co, Ci, P, ws, dW, ST(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// OutConv + MSE / metrics + OutConv backward in one pass (training_step: lit.py:32-38 on unet.py:86-92)
+// ------------------------------------------------------------------------------------------------
+static void outc_loss_grid(long n_img, int HW, int& gx, long& ipw, long& gy) {
+  gx = HW / 4096; if (gx < 1) gx = 1; if (gx > 16) gx = 16;
+  ipw = (n_img * gx + 8191) / 8192; if (ipw < 1) ipw = 1;
+  gy = (n_img + ipw - 1) / ipw;
+}
+extern "C" long mo_outc_loss_ws_floats(long n_img, int HW, int Ci, int Co) {
+  int gx; long ipw, gy; outc_loss_grid(n_img, HW, gx, ipw, gy);
+  return (long)gx * gy * ((long)Co * Ci + Co + 3) + 16;
+}
+extern "C" int mo_outc_loss_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
+                                int gsize, const float* W, const float* b, int Co, const float* target,
+                                const long long* target_off, long n_img, int HW, float* yhat, float* da, long dastride,
+                                float* ws, float* out4, int dtypes, void* stream) {
+  MO_CHECK_ARG(in && W && target && ws && out4 && Ci > 0 && Ci <= 4 && Co > 0 && Co <= 16 && n_img > 0 && HW > 0);
+  MO_CHECK_ARG((HW % 4) == 0 && (istride & 3) == 0 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)target) & 15) == 0 &&
+               (!da || ((dastride & 3) == 0 && (((uintptr_t)da) & 15) == 0)) && (!yhat || (((uintptr_t)yhat) & 15) == 0));
+  int gx; long ipw, gy; outc_loss_grid(n_img, HW, gx, ipw, gy);
+  MO_CHECK_ARG(gy <= 65535);
+  UtLossArgs a; a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize;
+  a.bfi = (dtypes & MO_BF_IN0) != 0; a.W = W; a.b = b; a.Co = Co; a.tgt = target;
+  a.tgt_off = reinterpret_cast<const long*>(target_off); a.tgt_stride = (long)Co * HW;
+  a.yhat = yhat; a.ys = (long)Co * HW; a.da = da; a.das = dastride; a.bfda = (dtypes & MO_BF_OUT) != 0; a.slab = ws;
+  a.n_img = n_img; a.HW = HW; a.img_per_wg = (int)ipw;
+  const double n_elem = (double)n_img * Co * HW;
+  a.inv_n2 = (float)(2.0 / n_elem);
+  hipStream_t st = ST(stream);
+  dim3 grid(gx, (unsigned)gy);
+  if (Co <= 1) hipLaunchKernelGGL((ut_outc_loss_kernel<1>), grid, dim3(256), 0, st, a);
+  else if (Co <= 4) hipLaunchKernelGGL((ut_outc_loss_kernel<4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ut_outc_loss_kernel<16>), grid, dim3(256), 0, st, a);
+  const int nw = Co * Ci, ncol = nw + Co + 3;
+  hipLaunchKernelGGL(ut_outc_loss_final_kernel, dim3(3), dim3(256), 0, st, ws, (int)(gx * gy), ncol, nw, Co, 0, n_elem,
+                     (const float*)nullptr, (float*)nullptr, (float*)nullptr, out4);
+  return mo_launch_status();
+}
+extern "C" int mo_outc_loss_bwd(const float* ws, long n_img, int HW, int Ci, int Co, const float* scale, float* dW,
+                                float* db, void* stream) {
+  MO_CHECK_ARG(ws && dW && Ci > 0 && Ci <= 4 && Co > 0 && Co <= 16 && n_img > 0 && HW > 0);
+  int gx; long ipw, gy; outc_loss_grid(n_img, HW, gx, ipw, gy);
+  const int nw = Co * Ci, ncol = nw + Co + 3;
+  hipLaunchKernelGGL(ut_outc_loss_final_kernel, dim3(nw + Co), dim3(256), 0, ST(stream), ws, (int)(gx * gy), ncol, nw, Co, 1,
+                     1.0, scale, dW, db, (float*)nullptr);
+  return mo_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1058,7 +1114,8 @@ __global__ void unet_act_bwd_param_kernel(const double* __restrict__ k12, long G
 // per group (k12 of the group from its partial rows), then the groups folded in a fixed order for dgamma / dbeta
 __global__ __launch_bounds__(256) void unet_act_bwd_final_param_kernel(const double* __restrict__ part, long G, int C,
                                                                        int gsize, int HW, int S, double* __restrict__ k12,
-                                                                       float* dgamma, float* dbeta) {
+                                                                       float* dgamma, float* dbeta,
+                                                                       const float* __restrict__ out_scale) {
   __shared__ double red[2][256];
   const int c = blockIdx.x;
   const double M = (double)gsize * HW;
@@ -1079,14 +1136,18 @@ __global__ __launch_bounds__(256) void unet_act_bwd_final_param_kernel(const dou
     if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { dgamma[c] = (float)(red[0][0] * M); dbeta[c] = (float)(red[1][0] * M); }
+  if (threadIdx.x == 0) {
+    const double os = out_scale ? (double)*out_scale : 1.0;   // (k12 stays at unit scale: the apply kernel scales dy)
+    dgamma[c] = (float)(red[0][0] * M * os); dbeta[c] = (float)(red[1][0] * M * os);
+  }
 }
 __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istride, int C, int H, int W, int gsize,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, const float* __restrict__ sc,
                                           const float* __restrict__ sh, const float* __restrict__ da, long dastride,
                                           const float* __restrict__ dp, long dpstride, const double* __restrict__ k12,
-                                          float* __restrict__ dy, long dystride, long total4, UaFlags f) {
+                                          float* __restrict__ dy, long dystride, long total4, UaFlags f,
+                                          const float* __restrict__ out_scale) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int Q = W >> 2;
@@ -1102,7 +1163,7 @@ __global__ void unet_act_bwd_apply_kernel(const float* __restrict__ y, long istr
   // the two group means are subtracted in double: rounded to fp32 their error would be the same for every pixel of
   // the group and come back multiplied by sum(x) in the weight gradient (measured 8e-4 of a gradient's scale)
   const double k1 = k12[(g * C + c) * 2], k2 = k12[(g * C + c) * 2 + 1];
-  const float gr = gamma[c] * rs;
+  const float gr = gamma[c] * rs * (out_scale ? *out_scale : 1.f);
   float4 o;
   o.x = gr * (float)((double)dz[0] - k1 - (double)((yv.x - mu) * rs) * k2);
   o.y = gr * (float)((double)dz[1] - k1 - (double)((yv.y - mu) * rs) * k2);
@@ -1158,7 +1219,8 @@ __global__ __launch_bounds__(256) void unet_act_bwd_apply2_kernel(const float* _
                                            const float* __restrict__ rstd, const float* __restrict__ sc,
                                            const float* __restrict__ sh, const float* __restrict__ da, long dastride,
                                            const float* __restrict__ dp, long dpstride, const double* __restrict__ k12,
-                                           float* __restrict__ dy, long dystride, long total8) {
+                                           float* __restrict__ dy, long dystride, long total8,
+                                           const float* __restrict__ out_scale) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total8) return;
   const int Q2 = W >> 3;
@@ -1173,7 +1235,7 @@ __global__ __launch_bounds__(256) void unet_act_bwd_apply2_kernel(const float* _
   unet_dz4_t<YB, DAB, DPB>(y, yoff, W, yy, q, s, t, da, daoff, dp, dpoff, yv0, d0);
   unet_dz4_t<YB, DAB, DPB>(y, yoff, W, yy, q + 1, s, t, da, daoff, dp, dpoff, yv1, d1);
   const double k1 = k12[(g * C + c) * 2], k2 = k12[(g * C + c) * 2 + 1];
-  const float gr = gamma[c] * rs;
+  const float gr = gamma[c] * rs * (out_scale ? *out_scale : 1.f);
   float4 o0, o1;
   o0.x = gr * (float)((double)d0[0] - k1 - (double)((yv0.x - mu) * rs) * k2);
   o0.y = gr * (float)((double)d0[1] - k1 - (double)((yv0.y - mu) * rs) * k2);
@@ -1196,7 +1258,7 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
                                const float* gamma, const float* mean, const float* rstd, const float* sc,
                                const float* sh, const float* da, long dastride, const float* dp, long dpstride,
                                float* dy, long dystride, float* dgamma, float* dbeta, float* ws, int dtypes,
-                               void* stream) {
+                               const float* out_scale, void* stream) {
   MO_CHECK_ARG(y && gamma && mean && rstd && sc && sh && dy && dgamma && dbeta && ws && (da || dp));
   MO_CHECK_ARG(C > 0 && n_img > 0 && n_img <= 65535 && gsize > 0 && (n_img % gsize) == 0);
   MO_CHECK_ARG(!dp || ((H % 2) == 0 && (Wd % 2) == 0));
@@ -1229,18 +1291,19 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
                        C, H, Wd, gsize, mean, rstd, sc, sh, da, dastride, dp, dpstride, part, fl);
   const long G = n_img / gsize;
   if (C <= 65535) {
-    hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(C), dim3(256), 0, st, part, G, C, gsize, HW, S, k12, dgamma, dbeta);
+    hipLaunchKernelGGL(unet_act_bwd_final_param_kernel, dim3(C), dim3(256), 0, st, part, G, C, gsize, HW, S, k12, dgamma, dbeta, out_scale);
   } else {
+    if (out_scale) return MO_EUNSUPPORTED;
     hipLaunchKernelGGL(unet_act_bwd_final_kernel, dim3(mo_cdiv(G * C, 256)), dim3(256), 0, st, part, G, C, gsize, HW, S, k12);
     hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
   }
   const long total4 = n_img * C * (HW / 4);
 #define UA_APPLY2(YB, DAB, DPB, DYB) hipLaunchKernelGGL((unet_act_bwd_apply2_kernel<YB, DAB, DPB, DYB>), dim3(mo_cdiv(total4 / 2, 256)), \
-    dim3(256), 0, st, y, istride, C, H, Wd, gsize, gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4 / 2)
+    dim3(256), 0, st, y, istride, C, H, Wd, gsize, gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4 / 2, out_scale)
   if (two) { if (fl.dy) UA_DISPATCH3(UA_APPLY2, true); else UA_DISPATCH3(UA_APPLY2, false); }
   else
     hipLaunchKernelGGL(unet_act_bwd_apply_kernel, dim3(mo_cdiv(total4, 256)), dim3(256), 0, st, y, istride, C, H, Wd, gsize,
-                       gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4, fl);
+                       gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4, fl, out_scale);
 #undef UA_APPLY2
 #undef UA_PARTIAL2
 #undef UA_DISPATCH3

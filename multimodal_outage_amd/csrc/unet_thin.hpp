@@ -316,3 +316,153 @@ __global__ __launch_bounds__(256) void ut_convt_wgrad_kernel(UtTArgs a) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// OutConv + MSE / metrics + OutConv backward in ONE pass (training_step, lit.py:32-38 on unet.py:86-92).
+// The prediction yhat = OutConv(act(v)) is consumed only by the loss (lit.py:33-38 never returns it), so per 4-pixel
+// piece a thread forms the Co outputs in registers, reads the Co target values, accumulates the three sums of
+// lit.py:33-38 (squared error, absolute error, absolute percentage error), forms d = 2 (yhat - y) / n and at once
+//   * the data gradient of the 1x1 conv   da[ci] = sum_co W[co][ci] d[co]        (stored as the input view is), and
+//   * its weight / bias gradient sums      dW[co][ci] += d[co] act(v)[ci],  db[co] += d[co]   (slab row per workgroup).
+// Neither yhat nor dL/dyhat is ever written (optionally yhat, for callers that want it): 70 + 457 + 70 MB instead of
+// the 4 x 457 MB + 2 x 70 MB of OutConv forward -> loss kernel -> OutConv data gradient + weight gradient (config 3).
+// Everything is linear in the upstream gradient of the loss, which is only known in backward: the sums are formed for
+// d loss = 1 and the consumers (mo_unet_act_bwd's `out_scale`, the final reduction below) multiply by it.
+// The target is addressed through per-image element offsets (lit.py:31 hands a permuted view of the batch).
+// ------------------------------------------------------------------------------------------------
+struct UtLossArgs {
+  const float* in; long is; int Ci;                      // activated input view (Ci <= 4 channels)
+  const float* sc; const float* sh; int relu, gsize, bfi;
+  const float* W; const float* b; int Co;                // (Co, Ci), (Co); Co <= 16
+  const float* tgt; const long* tgt_off; long tgt_stride;   // target planes: image img at tgt + (tgt_off ? tgt_off[img] : img * tgt_stride)
+  float* yhat; long ys;                                  // optional prediction (fp32), else null
+  float* da; long das; int bfda;                         // gradient w.r.t. the activated input view (unit upstream gradient)
+  float* slab;                                           // [workgroups][Co*Ci + Co + 3]
+  long n_img; int HW, img_per_wg; float inv_n2;          // 2 / (number of elements of yhat)
+};
+template <int CO>
+__global__ __launch_bounds__(256) void ut_outc_loss_kernel(UtLossArgs a) {
+  constexpr int CI = 4, NS = CO * CI + CO + 3;
+  __shared__ float wsm[CO][CI];
+  __shared__ float bsm[CO];
+  __shared__ float red[4][NS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < CO * CI; i += 256) {
+    const int co = i / CI, ci = i - co * CI;
+    wsm[co][ci] = (co < a.Co && ci < a.Ci) ? a.W[(long)co * a.Ci + ci] : 0.f;
+  }
+  if (tid < CO) bsm[tid] = (a.b && tid < a.Co) ? a.b[tid] : 0.f;
+  __syncthreads();
+  float accw[CO][CI], accb[CO], s_sq = 0.f, s_abs = 0.f, s_ape = 0.f;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    accb[co] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) accw[co][ci] = 0.f;
+  }
+  const long img0 = (long)blockIdx.y * a.img_per_wg, img1 = min(img0 + a.img_per_wg, a.n_img);
+  for (long img = img0; img < img1; ++img) {
+    const long grp = img / a.gsize;
+    const float* tg = a.tgt + (a.tgt_off ? a.tgt_off[img] : img * a.tgt_stride);
+    for (int p = (blockIdx.x * 256 + tid) * 4; p < a.HW; p += gridDim.x * 1024) {
+      float x[CI][4];
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci < a.Ci) {
+          v = ua_ld4(a.in, img * a.is + (long)ci * a.HW + p, a.bfi);
+          if (a.sc) {
+            const float s = a.sc[grp * a.Ci + ci], t = a.sh[grp * a.Ci + ci];
+            v.x = v.x * s + t; v.y = v.y * s + t; v.z = v.z * s + t; v.w = v.w * s + t;
+          }
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        x[ci][0] = v.x; x[ci][1] = v.y; x[ci][2] = v.z; x[ci][3] = v.w;
+      }
+      float dacc[CI][4];
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dacc[ci][k] = 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        if (co < a.Co) {
+          const float4 t4 = *reinterpret_cast<const float4*>(tg + (long)co * a.HW + p);
+          const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+          float o[4], d[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float s = bsm[co];
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) s += wsm[co][ci] * x[ci][k];
+            o[k] = s;
+            const float e = s - tv[k], ae = fabsf(e);
+            s_sq += e * e; s_abs += ae; s_ape += ae / fmaxf(fabsf(tv[k]), 1.17e-06f);
+            d[k] = e * a.inv_n2;
+          }
+          if (a.yhat) *reinterpret_cast<float4*>(a.yhat + img * a.ys + (long)co * a.HW + p) = make_float4(o[0], o[1], o[2], o[3]);
+          accb[co] += (d[0] + d[1]) + (d[2] + d[3]);
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci) {
+            const float w = wsm[co][ci];
+            accw[co][ci] += (d[0] * x[ci][0] + d[1] * x[ci][1]) + (d[2] * x[ci][2] + d[3] * x[ci][3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dacc[ci][k] += w * d[k];
+          }
+        }
+      }
+      if (a.da) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+          if (ci < a.Ci) ua_st4(a.da, img * a.das + (long)ci * a.HW + p, make_float4(dacc[ci][0], dacc[ci][1], dacc[ci][2], dacc[ci][3]), a.bfda);
+      }
+    }
+  }
+  // fixed-order reduction: wave shuffles, the four waves through LDS, one slab row per workgroup
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    float v;
+    if (i < CO * CI) v = accw[i / CI][i % CI];
+    else if (i < CO * CI + CO) v = accb[i - CO * CI];
+    else v = (i == NS - 3) ? s_sq : (i == NS - 2) ? s_abs : s_ape;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  const int nw = a.Co * a.Ci, nout = nw + a.Co + 3;
+  float* row = a.slab + ((long)blockIdx.y * gridDim.x + blockIdx.x) * nout;
+  for (int i = tid; i < nout; i += 256) {
+    int src;
+    if (i < nw) { const int co = i / a.Ci, ci = i - co * a.Ci; src = co * CI + ci; }
+    else src = CO * CI + (i - nw) + (i >= nw + a.Co ? CO - a.Co : 0);
+    row[i] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+  }
+}
+// column sums of the slab in double, fixed order.  mode 0 (forward): the last three columns -> out4 = {mse, mae, mape,
+// rmse} (lit.py:33-38).  mode 1 (backward): the first nw + Co columns, times the upstream gradient *scale -> dW, db.
+__global__ __launch_bounds__(256) void ut_outc_loss_final_kernel(const float* __restrict__ slab, int nrow, int ncol, int nw, int Co,
+                                                                 int mode, double n_elem, const float* __restrict__ scale,
+                                                                 float* __restrict__ dW, float* __restrict__ db,
+                                                                 float* __restrict__ out4) {
+  __shared__ double sm[256];
+  const int col = mode ? blockIdx.x : nw + Co + blockIdx.x;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < nrow; r += 256) s += (double)slab[(long)r * ncol + col];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (mode) {
+      const double v = sm[0] * (scale ? (double)*scale : 1.0);
+      if (col < nw) dW[col] = (float)v; else if (db) db[col - nw] = (float)v;
+    } else {
+      const double m = sm[0] / n_elem;
+      out4[blockIdx.x] = (float)m;
+      if (blockIdx.x == 0) out4[3] = (float)sqrt(m);
+    }
+  }
+}

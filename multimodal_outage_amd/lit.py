@@ -60,11 +60,13 @@ class LitModified_UNET(_Base):
         super().__init__()
         self.st_gnn = st_gnn
         self.horizon = horizon
-        self.model = Modified_UNET(st_gnn=self.st_gnn, horizon=self.horizon, input_channels=1, output_channels=1,
-                                   **model_kwargs).to(device=device)
+        kw = dict(input_channels=1, output_channels=1)                  # lit.py:23; BASELINE config 3 passes 13 / 13 and
+        kw.update(model_kwargs)                                         # image_dimension=256 through model_kwargs
+        self.model = Modified_UNET(st_gnn=self.st_gnn, horizon=self.horizon, **kw).to(device=device)
         self._dev = torch.device(device)
         self.verbose = verbose
         self.logged = {}
+        self.fused_loss = True      # False: model(x) -> yhat -> mo_mse_metrics, as two separate steps
 
     if _Base is nn.Module:
         @property
@@ -77,6 +79,10 @@ class LitModified_UNET(_Base):
     def _step(self, batch, prefix):
         x, y, x_time = batch
         x, y = (tensor.to(self.device).permute(0, 2, 1, 3, 4, 5) for tensor in (x, y))     # lit.py:31
+        if self.fused_loss:
+            # forward + MSE / MAE / MAPE / RMSE (lit.py:32-38) with the last layer fused into the loss: yhat, which the
+            # step never returns, is not materialised (Modified_UNET.forward_loss); y stays the permuted view
+            return self.model.forward_loss(x, x_time.to(self.device), y)
         yhat = self.model(x, x_time.to(self.device))
         loss, mae, mape, rmse = mse_and_metrics(yhat, y)
         return loss, mae, mape, rmse

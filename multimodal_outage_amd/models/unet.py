@@ -199,6 +199,42 @@ class Modified_UNET(nn.Module):
 
     def forward(self, input, time_dim):
         """unet.py:219-231.  input: (B, n_counties, H, Cin, S, S); time_dim: (B, n_counties, H, 64)."""
+        return self._run(input, time_dim, None)
+
+    def forward_loss(self, input, time_dim, target):
+        """forward + the loss and metrics of training_step in one go (lit.py:32-38): returns (mse, mae, mape, rmse) as 0-d
+        tensors, mse differentiable.  Same arithmetic as ``mse_and_metrics(self(input, time_dim), target)``, but the last
+        layer (OutConv, unet.py:86-92) is fused with the loss and with its own backward: the prediction -- which
+        training_step never returns -- and dL/dyhat are not written to HBM (mo_outc_loss_fwd).  ``target`` may be any
+        view whose images are contiguous, e.g. the permuted batch of lit.py:31 (addressed through per-image offsets,
+        no copy)."""
+        out4 = self._run(input, time_dim, target)
+        return out4[0], out4[1].detach(), out4[2].detach(), out4[3].detach()
+
+    def _image_offsets(self, t, n_img):
+        """Per-image element offsets of a (B, NC, H, C, S, S) view whose images are contiguous, or None when the images
+        lie in logical order; cached per (shape, strides) -- the table is uploaded once, not per step."""
+        C, S = t.shape[3], t.shape[4]
+        if t.stride()[3:] != (S * S, S, 1):
+            return False
+        img = C * S * S
+        B, NC, H = t.shape[:3]
+        sb, sc, sh = t.stride()[:3]
+        if (sb, sc, sh) == (NC * H * img, H * img, img):
+            return None
+        key = (tuple(t.shape[:3]), (sb, sc, sh), t.device)
+        cache = self.__dict__.setdefault('_mo_offsets', {})
+        off = cache.get(key)
+        if off is None:
+            b = torch.arange(B).view(B, 1, 1) * sb
+            c = torch.arange(NC).view(1, NC, 1) * sc
+            h = torch.arange(H).view(1, 1, H) * sh
+            off = cache[key] = (b + c + h).reshape(-1).to(torch.int64).to(t.device)
+            if len(cache) > 8:
+                cache.pop(next(iter(cache)))
+        return off
+
+    def _run(self, input, time_dim, target):
         if not input.is_cuda:
             raise RuntimeError('Modified_UNET runs on the MI355X HIP path only (no CPU fallback)')
         B, NC, H, Cin, S, _ = input.shape
@@ -213,7 +249,13 @@ class Modified_UNET(nn.Module):
                      fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None),
                      act_dtype=getattr(self, 'act_dtype', 'f32'))
         st_e = dict(state, names=enc_names)
-        outs = UnetEncodeFn.apply(st_e, input.reshape(n, Cin, S, S).float(), *[named[k] for k in enc_names])
+        x_off = self._image_offsets(input, n) if input.dtype == torch.float32 else False
+        if x_off is None or x_off is False or S < 32 or S % 4 or Cin > 32:
+            x_in = input.reshape(n, Cin, S, S).float()        # (a view when the images lie in logical order, else a copy)
+        else:
+            x_in = input                                      # permuted batch view (lit.py:31): the first conv and its
+            st_e['x_off'] = x_off                             # weight gradient read it in place through image offsets
+        outs = UnetEncodeFn.apply(st_e, x_in, *[named[k] for k in enc_names])
         feat, fms = outs[0], outs[1:]
         feat = feat.view(B, NC, H, feature_vector_size)
         zs = []
@@ -225,6 +267,18 @@ class Modified_UNET(nn.Module):
         z = torch.stack(zs).reshape(n, feature_vector_size)
         st_d = dict(state, names=dec_names, skip_meta=st_e['skip_meta'],
                     fc_dropout=self.decoder.dropout1.p)
+        if target is not None:
+            Cout = self.expansion.outc.conv.weight.shape[0]
+            assert tuple(target.shape) == (B, NC, H, Cout, S, S), 'target must have the shape of the prediction'
+            target = target.float()
+            off = self._image_offsets(target, n)
+            if off is False or Cin > 0 and self.expansion.outc.conv.weight.shape[1] > 4 or Cout > 16:
+                # (images not contiguous, or an OutConv wider than the fused kernel serves: the unfused tail)
+                from ..lit import mse_and_metrics
+                out = UnetDecodeFn.apply(st_d, z, *fms, *[named[k] for k in dec_names])
+                return torch.stack(mse_and_metrics(out.view(B, NC, H, out.shape[1], S, S), target))
+            st_d.update(target=target, target_off=off)
+            return UnetDecodeFn.apply(st_d, z, *fms, *[named[k] for k in dec_names])
         out = UnetDecodeFn.apply(st_d, z, *fms, *[named[k] for k in dec_names])
         return out.view(B, NC, H, out.shape[1], S, S)
 

@@ -63,8 +63,9 @@ DEC_CH = ((64, 32), (32, 16), (16, 8), (8, 4))      # up1..4   (unet.py:178-181)
 class View:
     """An activated view: raw NCHW tensor + per-(group,channel) folded BatchNorm affine + ReLU."""
 
-    def __init__(self, t, C, H, W, sc=None, sh=None):
+    def __init__(self, t, C, H, W, sc=None, sh=None, off=None):
         self.t, self.C, self.H, self.W, self.sc, self.sh = t, C, H, W, sc, sh
+        self.off = off        # optional int64 per-image element offsets (the network input as a permuted view, lit.py:31)
 
     @property
     def istride(self):
@@ -76,7 +77,8 @@ class View:
         return int(self.t.dtype == torch.bfloat16)
 
     def args(self):
-        return (L.ptr(self.t), self.C, self.istride, L.ptr(self.sc), L.ptr(self.sh), 1 if self.sc is not None else 0)
+        return (self.t.data_ptr() if self.off is not None else L.ptr(self.t), self.C, self.istride, L.ptr(self.sc),
+                L.ptr(self.sh), 1 if self.sc is not None else 0)
 
 
 _NOVIEW = (None, 0, 0, None, None, 0)
@@ -129,7 +131,7 @@ def _conv_bn(p, wkey, bnkey, views, Co, n, gs, training, bufs, dev, out_bf=False
     ntile = (L.load().mo_conv3x3_stats_tiles2(v0.C, views[1].C if len(views) > 1 else 0, Co, n, H, W, dt)
              if training else 0)
     stats = _empty(n, ntile, Co, 2, dev=dev) if ntile else None
-    L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, L.ptr(stats), dt, st)
+    L.call('mo_conv3x3_fwd', *v0.args(), *a1, gs, L.ptr(p[wkey]), Co, n, H, W, L.ptr(y), Co * H * W, L.ptr(stats), dt, L.ptr(v0.off), st)
     G = n // gs
     aff = _empty(4, G, Co, dev=dev)            # scale, shift, mean, rstd
     if training and not ntile:
@@ -172,7 +174,8 @@ def _dastride(t):
     return t, t.stride(0)
 
 
-def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=True, dx_bf=False, lane=None):
+def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=True, dx_bf=False, lane=None,
+                    da_scale=None):
     """Backward of DoubleConv.  da: gradient w.r.t. the activated output view (may be a channel slice of
     a wider buffer), dp: gradient w.r.t. its 2x2 max-pooled version.  Returns the gradient w.r.t. the
     (activated) channel-concatenated input, shape (n, C0+C1, H, W), or None."""
@@ -182,7 +185,7 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
     HW = H * W
     math = L.BF_MATH * int(sv.get('math', False))
 
-    def act_bwd(y, aff, bnkey, da_t, dp_t):
+    def act_bwd(y, aff, bnkey, da_t, dp_t, scale=None):
         dy = _empty(n, Co, H, W, dev=dev, bf=_is_bf(y))          # the gradient of a conv output is stored as the output is
         dg = grads.buf(bnkey + '.weight', (Co,))
         db = grads.buf(bnkey + '.bias', (Co,))
@@ -191,7 +194,8 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
         L.call('mo_unet_act_bwd', L.ptr(y), Co * HW, Co, n, H, W, gs, L.ptr(p[bnkey + '.weight']), L.ptr(aff[2]),
                L.ptr(aff[3]), L.ptr(aff[0]), L.ptr(aff[1]), da_t.data_ptr() if da_t is not None else None, das,
                L.ptr(dp_t), (Co * HW) // 4, L.ptr(dy), Co * HW, L.ptr(dg), L.ptr(db), L.ptr(ws),
-               (L.BF_IN0 * _is_bf(y)) | (L.BF_IN1 * _is_bf(da_t)) | (L.BF_DP * _is_bf(dp_t)) | (L.BF_OUT * _is_bf(dy)), st)
+               (L.BF_IN0 * _is_bf(y)) | (L.BF_IN1 * _is_bf(da_t)) | (L.BF_DP * _is_bf(dp_t)) | (L.BF_OUT * _is_bf(dy)),
+               L.ptr(scale), st)
         return dy
 
     lane = lane or _Lane(dev, False)
@@ -205,7 +209,7 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
         def fn(ls):
             ws = lane.keep(torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * HW), device=dev, dtype=torch.float32))
             L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * HW, Co, *views[0].args(), *a1, gs, n, H, W, L.ptr(dW),
-                   L.ptr(ws), dt, ls)
+                   L.ptr(ws), dt, L.ptr(views[0].off), ls)
         lane.run(fn, reads=[dy, dW] + [t for v in views for t in (v.t, v.sc, v.sh)])
 
     def dgrad(dy, Wt, out_bf):
@@ -215,14 +219,16 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
         if math and lib.mo_conv3x3_bf16_route(Co, Ci, n, H, W):
             # the bf16 matrix-pipe kernel reads the forward weights transposed + flipped in place
             L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wt), Ci, n, H, W,
-                   L.ptr(dx), Ci * HW, None, dt | math | L.W_FLIP, st)
+                   L.ptr(dx), Ci * HW, None, dt | math | L.W_FLIP, None, st)
             return dx
         Wf = _flip(Wt, dev)
         L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wf), Ci, n, H, W,
-               L.ptr(dx), Ci * HW, None, dt, st)
+               L.ptr(dx), Ci * HW, None, dt, None, st)
         return dx
 
-    dy2 = act_bwd(sv['y2'], sv['aff2'], pre + '.double_conv.4', da, dp)
+    # da_scale (device scalar): `da` was formed for an upstream loss gradient of 1 (mo_outc_loss_fwd); everything behind
+    # this activation backward is linear in it, so it is applied once, here
+    dy2 = act_bwd(sv['y2'], sv['aff2'], pre + '.double_conv.4', da, dp, da_scale)
     wgrad(dy2, [sv['v1']], pre + '.double_conv.3.weight')
     da1 = dgrad(dy2, p[pre + '.double_conv.3.weight'], _is_bf(sv['y1']))      # consumed by y1's activation backward
     dy1 = act_bwd(sv['y1'], sv['aff1'], pre + '.double_conv.1', da1, None)
@@ -337,16 +343,24 @@ class UnetEncodeFn(torch.autograd.Function):
     def forward(ctx, state, x, *params):
         p = dict(zip(state['names'], params))
         dev = x.device
-        n, Cin, S, _ = x.shape
         gs, training, bufs = state['gsize'], state['training'], state['bufs']
-        x = x.contiguous()
+        x_off = None
+        if x.dim() == 6:
+            # the (B, NC, H, Cin, S, S) batch as a permuted view (lit.py:31): read in place through per-image offsets
+            n, (Cin, S) = x.shape[0] * x.shape[1] * x.shape[2], x.shape[3:5]
+            x_off = state['x_off']
+            ctx.x_shape = tuple(x.shape)
+        else:
+            n, Cin, S, _ = x.shape
+            x = x.contiguous()
+            ctx.x_shape = None
         st = L.stream()
         saved = []
         mode = state.get('act_dtype', 'f32')      # 'bf16': conv outputs / gradients of the large levels stored as bf16
         b0 = bf_ok(mode, 4, S, S)
         math = mode == 'bf16'
-        sv, v = double_conv_fwd(p, 'contraction.inc', [View(x, Cin, S, S)], 4, n, gs, training, bufs, dev, bf=(b0, b0),
-                                math=math)
+        sv, v = double_conv_fwd(p, 'contraction.inc', [View(x, Cin, S, S, off=x_off)], 4, n, gs, training, bufs, dev,
+                                bf=(b0, b0), math=math)
         saved.append(sv)
         views = [v]
         for k, (ci, co) in enumerate(ENC_CH, 1):
@@ -400,6 +414,8 @@ class UnetEncodeFn(torch.autograd.Function):
             dp = double_conv_bwd(p, saved[k], n, gs, grads, dev, da=dfm[k], dp=dp, need_input_grad=need,
                                  dx_bf=bool(k > 0 and saved[k]['views'][0].bf), lane=lane)
         lane.join()
+        if dp is not None and ctx.x_shape is not None:
+            dp = dp.view(ctx.x_shape)
         return (None, dp) + grads.result(state['names'])
 
 
@@ -438,10 +454,24 @@ class UnetDecodeFn(torch.autograd.Function):
             v = vn
         Wo, bo = p['expansion.outc.conv.weight'], p['expansion.outc.conv.bias']
         Cout = Wo.shape[0]
+        ctx.state, ctx.p, ctx.fc_sv, ctx.ups, ctx.vlast, ctx.n = state, p, fc_sv, ups, v, n
+        tgt = state.get('target')
+        ctx.fused_loss = tgt is not None
+        if tgt is not None:
+            # training_step (lit.py:32-38): OutConv + MSE / MAE / MAPE + OutConv's data and weight gradient sums in one
+            # pass; yhat and dL/dyhat are never written (mo_outc_loss_fwd)
+            HW = v.H * v.W
+            da = _empty(n, v.C, v.H, v.W, dev=dev, bf=bool(v.bf))
+            ws = torch.empty(L.load().mo_outc_loss_ws_floats(n, HW, v.C, Cout), device=dev, dtype=torch.float32)
+            out4 = torch.empty(4, device=dev, dtype=torch.float32)
+            L.call('mo_outc_loss_fwd', L.ptr(v.t), v.istride, v.C, L.ptr(v.sc), L.ptr(v.sh), 1, gs, L.ptr(Wo), L.ptr(bo),
+                   Cout, tgt.data_ptr(), L.ptr(state.get('target_off')), n, HW, None, L.ptr(da), v.C * HW, L.ptr(ws),
+                   L.ptr(out4), (L.BF_IN0 * v.bf) | (L.BF_OUT * v.bf), st)
+            ctx.loss_da, ctx.loss_ws = da, ws
+            return out4
         out = _empty(n, Cout, v.H, v.W, dev=dev)
         L.call('mo_nchw_conv1x1_fwd', L.ptr(v.t), v.istride, v.C, L.ptr(v.sc), L.ptr(v.sh), 1, gs, L.ptr(Wo), L.ptr(bo),
                Cout, n, v.H * v.W, L.ptr(out), Cout * v.H * v.W, L.BF_IN0 * v.bf, st)
-        ctx.state, ctx.p, ctx.fc_sv, ctx.ups, ctx.vlast, ctx.n = state, p, fc_sv, ups, v, n
         return out
 
     @staticmethod
@@ -459,6 +489,10 @@ class UnetDecodeFn(torch.autograd.Function):
         dWo = grads.buf('expansion.outc.conv.weight', Wo.shape)
         dbo = grads.buf('expansion.outc.conv.bias', (Cout,))
         lane = _Lane(dev)
+        if ctx.fused_loss:
+            # dout = d / d(mse, mae, mape, rmse): its first element is the upstream gradient of the loss, a device scalar the
+            # first activation backward and the OutConv weight-gradient reduction multiply by
+            return UnetDecodeFn._backward_body(ctx, grads, lane, ctx.loss_da, dout, dWo, dbo)
 
         def outc_wgrad(ls):
             ws = lane.keep(torch.empty(max(lib.mo_unet_wgrad_ws_floats(Cout, C4, n * HW), n * Cout * 2), device=dev,
@@ -469,11 +503,26 @@ class UnetDecodeFn(torch.autograd.Function):
         da = _empty(n, C4, v.H, v.W, dev=dev, bf=bool(v.bf))
         L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW,
                L.BF_OUT * v.bf, st)
+        return UnetDecodeFn._backward_body(ctx, grads, lane, da, None, None, None)
+
+    @staticmethod
+    def _backward_body(ctx, grads, lane, da, loss_scale, dWo, dbo):
+        state, p, n, v = ctx.state, ctx.p, ctx.n, ctx.vlast
+        lib = L.load()
+        gs = state['gsize']
+        dev = da.device
+        st = L.stream()
+        if loss_scale is not None:
+            Cout, C4 = dWo.shape[0], dWo.shape[1]
+            ws = ctx.loss_ws
+            lane.run(lambda ls: L.call('mo_outc_loss_bwd', L.ptr(ws), n, v.H * v.W, C4, Cout, L.ptr(loss_scale), L.ptr(dWo),
+                                       L.ptr(dbo), ls), reads=[ws, loss_scale, dWo, dbo])
         dfm = [None] * 4
         for k in (4, 3, 2, 1):
             up = ctx.ups[k - 1]
             ci, H, vin = up['ci'], up['H'], up['vin']
-            dcat = double_conv_bwd(p, up['dc'], n, gs, grads, dev, da=da, dp=None, lane=lane)     # (n, ci, 2H, 2H)
+            dcat = double_conv_bwd(p, up['dc'], n, gs, grads, dev, da=da, dp=None, lane=lane,
+                                   da_scale=loss_scale if k == 4 else None)     # (n, ci, 2H, 2H)
             C0 = ci // 2
             dfm[4 - k] = dcat[:, :C0]
             du = dcat[:, C0:]

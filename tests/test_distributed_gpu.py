@@ -89,3 +89,22 @@ def test_gwnet_overlapped_allreduce_two_ranks_one_gpu():
     for rank, announced, err, scale in res:
         assert announced >= 2, announced            # at least the mid-backward bucket and the end-of-backward one
         assert err <= 1e-6 * scale + 1e-9, (rank, err, scale)
+
+
+def test_bench_plain_two_rank_launch_on_one_gpu():
+    """`python bench.py --gpus 2` started plainly (no torchrun): the launcher starts two ranks that share this box's GPU
+    (gloo transport, toy graph), the real step runs on both, rank 0 prints the one line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--nodes', '320',
+                        '--batch', '2', '--steps', '2', '--warmup', '1', '--no-unet'], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 4 and line['value'] > 0
+    assert 'roofline' in line and abs(line['loss'] - 1.0) < 0.5

@@ -621,3 +621,41 @@ def test_helper_classes_nconv_linear_gcn_vs_oracle():
     assert_close(yg, ref, 2e-5, 1e-4, 'gcn')
     with pytest.raises(RuntimeError):
         nconv()(x, A1)                    # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize('mode,tol', [('f32', 1e-4), ('bf16', 1e-2)])
+def test_gwnet_follows_the_reference_training_trajectory(mode, tol):
+    """Both numeric modes against a trajectory of the REFERENCE's own gwnet class body (tools/make_goldens.py traj_gwnet:
+    BASELINE config 2 at N=300 -- (4,32,300,12) windows, K=2, two static supports + adaptive, dropout 0 -- six steps of
+    torch.optim.Adam(1e-3), a fresh seeded batch per step): per-step loss within 1e-4 (fp32) / 1e-2 (bf16 throughput mode)
+    relative, parameters after the last step within 2.5e-3 in max norm, BatchNorm running statistics 1e-3 / 2e-2."""
+    from multimodal_outage_amd.trainer import FlatTrainer
+    G = golden('traj_gwnet_C2s')
+    seed, N = int(G['seed']), 300
+    A = P.knn_graph(N, seed=2)
+    cfg = dict(N=N, in_dim=32, out_dim=12, K=2, seed=seed)
+    m = _model(cfg, [gwnet_ref.asym_adj(A), gwnet_ref.asym_adj(A.T)]).train()
+    m.dense_dtype = mode
+    tr = FlatTrainer(m, lr=1e-3).attach()
+    losses = []
+    for i in range(int(G['steps'])):
+        x = rand(seed + 10 + i, (4, 32, N, 12)).cuda()
+        tr.zero_grad()
+        y = m(x)
+        loss = F.mse_loss(y, rand(seed + 70 + i, tuple(y.shape)).cuda())
+        loss.backward()
+        tr.allreduce()
+        tr.step()
+        losses.append(float(loss))
+    print('gwnet trajectory', mode, [round(v, 6) for v in losses], 'reference', [round(float(v), 6) for v in G['losses']])
+    for a, b in zip(losses, G['losses']):
+        assert abs(a - b) <= tol * abs(b), (mode, losses, list(G['losses']))
+    for key in G.files:
+        if key.startswith('p/'):
+            v = dict(m.named_parameters())[key[2:]].detach().float().cpu().numpy().reshape(-1)
+            got = v[::max(1, v.size // 512)][:512]
+            assert float(np.abs(got - G[key]).max()) <= 2.5e-3, key
+    sd = m.state_dict()
+    for key in G.files:
+        if key.startswith('buf/') and 'num_batches' not in key:
+            assert_close(sd[key[4:]].float(), G[key], 1e-3 if mode == 'f32' else 2e-2, 1e-3 if mode == 'f32' else 2e-2, key)

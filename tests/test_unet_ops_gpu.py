@@ -59,7 +59,7 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
     ntile = lib.mo_conv3x3_stats_tiles(Co, n, H, W)
     stats = torch.full((n, max(ntile, 1), Co, 2), float('nan'), device='cuda')
     L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(dev(Wt.detach())), Co, n, H, W, L.ptr(out), Co * H * W,
-           L.ptr(stats) if ntile else None, (L.BF_IN0 | L.BF_OUT) if bf else 0, L.stream())
+           L.ptr(stats) if ntile else None, (L.BF_IN0 | L.BF_OUT) if bf else 0, None, L.stream())
     close(out.float(), ref, tol=4e-3 if bf else 1e-4, what='conv fwd')          # bf16 result: half an ulp = 2^-9
     if ntile:
         # BatchNorm statistics from the conv epilogue: per-tile (sum, sum of squares) rows add up to the per-image sums
@@ -77,7 +77,7 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
     for obf in ((0, 1) if bf else (0,)):                   # data gradient into an fp32 tensor (Up blocks) or a bf16 one
         dcat = torch.empty(n, Ci, H, W, device='cuda', dtype=torch.bfloat16 if obf else torch.float32)
         L.call('mo_conv3x3_fwd', L.ptr(dyd), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wf), Ci,
-               n, H, W, L.ptr(dcat), Ci * H * W, None, (L.BF_IN0 * bf) | (L.BF_OUT * obf), L.stream())
+               n, H, W, L.ptr(dcat), Ci * H * W, None, (L.BF_IN0 * bf) | (L.BF_OUT * obf), None, L.stream())
         dcat_ref = F.conv_transpose2d(dy, Wt.detach(), padding=1)
         close(dcat.float(), dcat_ref, tol=4e-3 if obf else 1e-4, what='conv bwd data')
         if C1:
@@ -85,7 +85,7 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
     dW = torch.empty(Co, Ci, 3, 3, device='cuda')
     ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * H * W), device='cuda')
     L.call('mo_conv3x3_bwd_weight', L.ptr(dyd), Co * H * W, Co, *args_in, gs, n, H, W, L.ptr(dW), L.ptr(ws),
-           (L.BF_DY | L.BF_IN0) if bf else 0, L.stream())
+           (L.BF_DY | L.BF_IN0) if bf else 0, None, L.stream())
     close(dW, Wt.grad, what='conv dW')
 
 
@@ -137,7 +137,7 @@ def _conv3x3_bf16_matrix_pipe(L, lib, n, gs, C0, C1, Co, H, W, bf):
     assert ntile == (W // (64 if W % 64 == 0 else 32)) * (H // 16)
     stats = torch.full((n, ntile, Co, 2), float('nan'), device='cuda')
     Wd_ = dev(Wt)
-    L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(Wd_), Co, n, H, W, L.ptr(out), Co * H * W, L.ptr(stats), dt, L.stream())
+    L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(Wd_), Co, n, H, W, L.ptr(out), Co * H * W, L.ptr(stats), dt, None, L.stream())
     close(out.float(), ref_q, tol=4e-3 if bf else 1e-3, what='conv fwd vs bf16-rounded operands')
     close(out.float(), ref, tol=1.5e-2, what='conv fwd vs fp32 conv')
     st = stats.cpu().double().sum(1)
@@ -151,7 +151,7 @@ def _conv3x3_bf16_matrix_pipe(L, lib, n, gs, C0, C1, Co, H, W, bf):
     for obf in ((0, 1) if bf else (0,)):
         dcat = torch.empty(n, Ci, H, W, device='cuda', dtype=torch.bfloat16 if obf else torch.float32)
         L.call('mo_conv3x3_fwd', L.ptr(dyd), Co, Co * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wd_), Ci,
-               n, H, W, L.ptr(dcat), Ci * H * W, None, L.BF_MATH | L.W_FLIP | (L.BF_IN0 * bf) | (L.BF_OUT * obf), L.stream())
+               n, H, W, L.ptr(dcat), Ci * H * W, None, L.BF_MATH | L.W_FLIP | (L.BF_IN0 * bf) | (L.BF_OUT * obf), None, L.stream())
         close(dcat.float(), dref_q, tol=4e-3 if obf else 1e-4, what='conv bwd data vs bf16-rounded operands')
     if bf and Co <= 16 and W % 64 == 0:
         # weight gradient: dy read straight into the B fragments, the activated input planar in LDS
@@ -160,7 +160,7 @@ def _conv3x3_bf16_matrix_pipe(L, lib, n, gs, C0, C1, Co, H, W, bf):
         dW = torch.full((Co, Ci, 3, 3), float('nan'), device='cuda')
         ws = torch.empty(lib.mo_unet_wgrad_ws_floats(Co, Ci * 9, n * H * W), device='cuda')
         L.call('mo_conv3x3_bwd_weight', L.ptr(dyd), Co * H * W, Co, *args_in, gs, n, H, W, L.ptr(dW), L.ptr(ws),
-               L.BF_MATH | L.BF_DY | L.BF_IN0, L.stream())
+               L.BF_MATH | L.BF_DY | L.BF_IN0, None, L.stream())
         close(dW, Wp.grad, tol=1e-3, what='conv dW vs bf16-rounded operands')
 
 
@@ -214,7 +214,7 @@ def test_group_bn_act_pool_fwd_bwd(L, n, gs, C, H, W, pool, use_da, bf):
     L.call('mo_unet_act_bwd', L.ptr(yd), C * H * W, C, n, H, W, gs, L.ptr(gd), L.ptr(aff[2]), L.ptr(aff[3]),
            L.ptr(aff[0]), L.ptr(aff[1]), L.ptr(dev(hb(da))) if use_da else None, C * H * W,
            L.ptr(dev(hb(dp))) if pool else None, C * (H // 2) * (W // 2), L.ptr(dy), C * H * W, L.ptr(dgam), L.ptr(dbet),
-           L.ptr(ws), (L.BF_IN0 | L.BF_IN1 | L.BF_DP | L.BF_OUT) if bf else 0, L.stream())
+           L.ptr(ws), (L.BF_IN0 | L.BF_IN1 | L.BF_DP | L.BF_OUT) if bf else 0, None, L.stream())
     close(dy.float(), y.grad, tol=4e-3 if bf else 1e-4, what='dy')
     close(dgam, gamma.grad, what='dgamma')
     close(dbet, beta.grad, what='dbeta')
@@ -360,7 +360,68 @@ def test_bf16_math_flag_falls_back_to_fp32_kernels(L, n, gs, C0, C1, Co, H, W):
     stats = torch.full((n, max(ntile, 1), Co, 2), float('nan'), device='cuda')
     L.call('mo_conv3x3_fwd', L.ptr(dev(x0)), C0, C0 * H * W, L.ptr(dev(sc0)), L.ptr(dev(sh0)), 1, L.ptr(dev(x1)) if C1 else None,
            C1, C1 * H * W, None, None, 0, gs, L.ptr(dev(Wt)), Co, n, H, W, L.ptr(out), Co * H * W,
-           L.ptr(stats) if ntile else None, L.BF_MATH, L.stream())
+           L.ptr(stats) if ntile else None, L.BF_MATH, None, L.stream())
     close(out, ref, tol=1e-4, what='conv fwd (fp32 fallback under MO_BF_MATH)')
     if ntile:
         close(stats.cpu().double().sum(1)[..., 0], ref.double().sum((2, 3)), tol=1e-5, what='epilogue sum')
+
+
+@pytest.mark.parametrize('n,gs,Ci,Co,HW,perm', [(4, 2, 4, 1, 256, False), (6, 2, 4, 13, 64 * 64, True), (3, 3, 4, 16, 5000, True),
+                                                (2, 1, 3, 3, 64, False), (12, 2, 4, 4, 128 * 128, True)])
+@pytest.mark.parametrize('bf', [0, 1])
+def test_outconv_loss_fused(L, n, gs, Ci, Co, HW, perm, bf):
+    """mo_outc_loss_fwd / _bwd (the tail of training_step, lit.py:32-38 on unet.py:86-92): OutConv + MSE / MAE / MAPE / RMSE,
+    the data gradient of the OutConv and its weight / bias gradients from one pass, for an upstream gradient handed in as
+    a device scalar; the target addressed through per-image offsets (a permuted batch).  Against torch on the CPU:
+    nn.MSELoss, the torchmetrics definitions restated in oracle/metrics_ref.py (parity unpinned for torchmetrics itself)."""
+    from oracle import metrics_ref
+    lib = L.load()
+    G = n // gs
+    x = rand(40, (n, Ci, HW, 1))
+    x = (x.to(torch.bfloat16).float() if bf else x).requires_grad_(True)
+    sc, sh = rand(41, (G, Ci)) * 0.3 + 1, rand(42, (G, Ci)) * 0.3
+    a = act_view(x, sc, sh, gs)
+    a.retain_grad()
+    Wt = rand(43, (Co, Ci, 1, 1)).requires_grad_(True)
+    b = rand(44, (Co,)).requires_grad_(True)
+    yhat = F.conv2d(a, Wt, b)
+    tgt = rand(45, tuple(yhat.shape))
+    tgt[0, 0, :5] = 0.0                                   # MAPE's clamp at 1.17e-6
+    loss = F.mse_loss(yhat, tgt)
+    upstream = 0.37
+    (loss * upstream).backward()
+    mae, mape, rmse = metrics_ref.metrics(yhat.detach(), tgt)
+    # the target as the permuted view of lit.py:31 would hand it: images stored in another order
+    if perm:
+        order = torch.randperm(n, generator=torch.Generator().manual_seed(7))
+        store = torch.empty_like(tgt)
+        store[order] = tgt                                # image i lives at slot order[i]
+        td = dev(store.reshape(n, Co, HW))
+        off = dev((order * (Co * HW)).to(torch.int64))
+    else:
+        td, off = dev(tgt.reshape(n, Co, HW)), None
+    xd, scd, shd = dev(x.detach().to(torch.bfloat16) if bf else x.detach()), dev(sc), dev(sh)
+    da = torch.full((n, Ci, HW), float('nan'), device='cuda').to(torch.bfloat16 if bf else torch.float32)
+    ws = torch.empty(lib.mo_outc_loss_ws_floats(n, HW, Ci, Co), device='cuda')
+    out4 = torch.empty(4, device='cuda')
+    yh = torch.empty(n, Co, HW, device='cuda')
+    L.call('mo_outc_loss_fwd', L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, L.ptr(dev(Wt.detach())),
+           L.ptr(dev(b.detach())), Co, L.ptr(td), L.ptr(off), n, HW, L.ptr(yh), L.ptr(da), Ci * HW, L.ptr(ws), L.ptr(out4),
+           (L.BF_IN0 | L.BF_OUT) * bf, L.stream())
+    close(yh, yhat.reshape(n, Co, HW), what='yhat')
+    o = out4.cpu()
+    assert abs(o[0] - loss.item()) <= 1e-5 * loss.item() and abs(o[1] - mae.item()) <= 1e-5 * mae.item()
+    assert abs(o[2] - mape.item()) <= 1e-4 * mape.item() and abs(o[3] - rmse.item()) <= 1e-5 * rmse.item()
+    # unit upstream gradient in da / the slab; the scale arrives as a device scalar
+    close(da.float() * upstream, a.grad.reshape(n, Ci, HW), tol=4e-3 if bf else 1e-4, what='da')
+    scale = dev(torch.tensor([upstream]))
+    dW = torch.empty(Co, Ci, device='cuda'); db = torch.empty(Co, device='cuda')
+    L.call('mo_outc_loss_bwd', L.ptr(ws), n, HW, Ci, Co, L.ptr(scale), L.ptr(dW), L.ptr(db), L.stream())
+    close(dW, Wt.grad.reshape(Co, Ci), what='dW')
+    close(db, b.grad, what='db')
+    # without the optional prediction the results are the same bits
+    da2 = torch.empty_like(da); out4b = torch.empty(4, device='cuda')
+    L.call('mo_outc_loss_fwd', L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, L.ptr(dev(Wt.detach())),
+           L.ptr(dev(b.detach())), Co, L.ptr(td), L.ptr(off), n, HW, None, L.ptr(da2), Ci * HW, L.ptr(ws), L.ptr(out4b),
+           (L.BF_IN0 | L.BF_OUT) * bf, L.stream())
+    assert torch.equal(out4, out4b) and torch.equal(da.view(torch.int16 if bf else torch.int32), da2.view(torch.int16 if bf else torch.int32))

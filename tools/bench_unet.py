@@ -21,28 +21,29 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--opt', action='append', default=[], help='name=value for mo_unet_set_option (A/B switches)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16', help="activation storage (Modified_UNET.act_dtype)")
+    ap.add_argument('--two-step', action='store_true', help='model(x) -> yhat -> loss kernel instead of the fused tail (A/B)')
     a = ap.parse_args()
     import multimodal_outage_amd._lib as L
     L.load()
     for o in a.opt:
         k, v = o.split('=')
         L.call('mo_unet_set_option', k.encode(), int(v))
-    from multimodal_outage_amd.models.unet import Modified_UNET
-    from multimodal_outage_amd.lit import mse_and_metrics
+    from multimodal_outage_amd.lit import LitModified_UNET
     from multimodal_outage_amd.trainer import FlatTrainer
     torch.manual_seed(42)
-    m = Modified_UNET('gwnet', a.horizon, input_channels=a.cin, output_channels=a.cin, image_dimension=a.size).cuda().train()
+    lit = LitModified_UNET('gwnet', a.horizon, 'cuda', input_channels=a.cin, output_channels=a.cin, image_dimension=a.size)
+    lit.fused_loss = not a.two_step
+    m = lit.model.train()
     m.act_dtype = a.dtype
     tr = FlatTrainer(m).attach()
     B, H, S = a.batch, a.horizon, a.size
-    x = torch.randn(B, 67, H, a.cin, S, S, device='cuda')
-    y = torch.randn(B, 67, H, a.cin, S, S, device='cuda')
+    x = torch.randn(B, H, 67, a.cin, S, S, device='cuda')        # the DataLoader's layout (utils.py:101-105)
+    y = torch.randn(B, H, 67, a.cin, S, S, device='cuda')
     td = torch.randn(B, 67, H, 64, device='cuda')
 
     def step():
         tr.zero_grad()
-        out = m(x, td)
-        loss, _, _, _ = mse_and_metrics(out, y)
+        loss = lit.training_step((x, y, td))                     # lit.py:29-43
         loss.backward()
         tr.allreduce()
         tr.step()

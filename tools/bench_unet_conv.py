@@ -70,20 +70,20 @@ for C0, bf0, C1, Co, S in LAYERS:
         dt = L.BF_IN0 * bf0 | L.BF_OUT | (L.BF_MATH if math else 0)
         nt = lib.mo_conv3x3_stats_tiles2(C0, C1, Co, n, S, S, dt)
         stats = torch.empty(n, nt, Co, 2, device=dev)
-        return lambda: L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(W), Co, n, S, S, L.ptr(out), Co * S * S, L.ptr(stats), dt, st)
+        return lambda: L.call('mo_conv3x3_fwd', *args_in, gs, L.ptr(W), Co, n, S, S, L.ptr(out), Co * S * S, L.ptr(stats), dt, None, st)
 
     def dgrad(math):
         if math:
             return lambda: L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * S * S, None, None, 0, None, 0, 0, None, None, 0, 1,
                                   L.ptr(W), Ci, n, S, S, L.ptr(dx), Ci * S * S, None,
-                                  L.BF_IN0 | L.BF_OUT | L.BF_MATH | L.W_FLIP, st)
+                                  L.BF_IN0 | L.BF_OUT | L.BF_MATH | L.W_FLIP, None, st)
         return lambda: L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * S * S, None, None, 0, None, 0, 0, None, None, 0, 1,
-                              L.ptr(Wf), Ci, n, S, S, L.ptr(dx), Ci * S * S, None, L.BF_IN0 | L.BF_OUT, st)
+                              L.ptr(Wf), Ci, n, S, S, L.ptr(dx), Ci * S * S, None, L.BF_IN0 | L.BF_OUT, None, st)
 
     def wgrad(math):
         dt = L.BF_DY | L.BF_IN0 * bf0 | (L.BF_MATH if math else 0)
         return lambda: L.call('mo_conv3x3_bwd_weight', L.ptr(dy), Co * S * S, Co, *args_in, gs, n, S, S, L.ptr(dW), L.ptr(ws),
-                              dt, st)
+                              dt, None, st)
 
     for op, mk, nbytes in (('fwd', fwd, in_bytes + px * Co * 2), ('dgrad', dgrad, px * (Co + Ci) * 2),
                            ('wgrad', wgrad, in_bytes + px * Co * 2)):

@@ -220,6 +220,126 @@ def modified_unet_case(name, B, H, seed, channels=1, size=128):
     print(name, 'loss', loss.item(), 'loss64', loss64.item())
 
 
+def _param_samples(module, tag, d, every=1):
+    """A strided sample (<= 512 values) of every `every`-th parameter tensor, keyed `<tag>/<name>`."""
+    for j, (k, v) in enumerate(module.named_parameters()):
+        if j % every:
+            continue
+        a = v.detach().numpy().reshape(-1)
+        d[f'{tag}/{k}'] = a[::max(1, a.size // 512)][:512].astype(np.float32).copy()
+
+
+def _unet_model(ns, schema, seed, H, channels, dtype=torch.float32):
+    m = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=channels, output_channels=channels)
+    P.load_into(m, P.seeded_values(schema, seed))
+    m.st_gnn.dropout = 0.0
+    for g in m.st_gnn.gconv:
+        g.dropout = 0.0
+    m.encoder.dropout1.p = 0.0
+    m.decoder.dropout1.p = 0.0
+    m = m.to(dtype).train()
+    m.st_gnn.supports = [s_.to(dtype) for s_ in m.st_gnn.supports]
+    return m
+
+
+def unet_trajectory_case(name, B, H, seed, channels=1, size=128, steps=6, with_f64=True):
+    """`steps` steps of torch.optim.Adam(lr=1e-3) (lit.py:59-61) on the reference's own Modified_UNET class bodies
+    (unet.py:201-231, training_step's forward + MSE of lit.py:29-33), a fresh seeded batch per step: per-step losses
+    and strided samples of the parameters after the last step; the same trajectory in float64 as the yardstick."""
+    sup = [torch.eye(67)]
+    ns_g = R.load_gwnet(False, sup)
+    ns = R.load_unet(ns_g['gwnet'], image_dimension=size)
+    schema = P.unet_schema(input_channels=channels, output_channels=channels, image_dimension=size)
+    d = dict(seed=np.int64(seed), steps=np.int64(steps), shape=np.array([B, 67, H, channels, size, size]))
+    for tag, dt in (('', torch.float32),) + ((('64', torch.float64),) if with_f64 else ()):
+        m = _unet_model(ns, schema, seed, H, channels, dt)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        losses = []
+        for i in range(steps):
+            x = rand(seed + 10 + i, (B, 67, H, channels, size, size)).to(dt)
+            tdim = rand(seed + 40 + i, (B, 67, H, 64)).to(dt)
+            tgt = rand(seed + 70 + i, (B, 67, H, channels, size, size)).to(dt)
+            opt.zero_grad(set_to_none=True)
+            loss = F.mse_loss(m(x, tdim), tgt)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+            print(name, tag or '32', 'step', i, 'loss', losses[-1], flush=True)
+        d['losses' + tag] = np.array(losses, dtype=np.float64)
+        _param_samples(m, 'p' + tag, d, every=3)
+        if not tag:
+            d.update(buffers(m))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+
+
+def gwnet_trajectory_case(name, *, B, N, T, in_dim, out_dim, K, static_supports, seed, steps=6):
+    """The same for gwnet alone in the shape-generic (B,C,N,T) form (BASELINE config 2 at N=300): Adam(1e-3), dropout 0,
+    a fresh seeded batch per step, fp32 and float64."""
+    d = dict(seed=np.int64(seed), steps=np.int64(steps))
+    for tag, dt in (('', torch.float32), ('64', torch.float64)):
+        sup_t = [torch.from_numpy(s).to(dt) for s in static_supports]
+        ns = R.load_gwnet(True, sup_t, n_counties=N)
+        g = ns['gwnet']('cpu', num_nodes=N, dropout=0.0, supports=sup_t, in_dim=in_dim, out_dim=out_dim, kernel_size=K)
+        schema = P.gwnet_schema(num_nodes=N, supports_len=len(sup_t) + 1, in_dim=in_dim, out_dim=out_dim, kernel_size=K)
+        P.load_into(g, P.seeded_values(schema, seed))
+        g = g.to(dt).train()
+        g.supports = sup_t
+        opt = torch.optim.Adam(g.parameters(), lr=1e-3)
+        losses = []
+        for i in range(steps):
+            x = rand(seed + 10 + i, (B, in_dim, N, T)).to(dt)
+            opt.zero_grad(set_to_none=True)
+            y = g(x)
+            tgt = rand(seed + 70 + i, tuple(y.shape)).to(dt)
+            loss = F.mse_loss(y, tgt)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+            print(name, tag or '32', 'step', i, 'loss', losses[-1], flush=True)
+        d['losses' + tag] = np.array(losses, dtype=np.float64)
+        _param_samples(g, 'p' + tag, d)
+        if not tag:
+            d.update(buffers(g))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+
+
+def unet_conditioned_grad_case(name='modified_unet_H7', seed=430, H=7, channels=1, size=128):
+    """A better-conditioned gradient golden for the bf16 mode's model-level check: BatchNorm groups of
+    H = 7 images (the reference default horizon) instead of 2, and a structured target (half the input -- an identity-like
+    task) instead of noise, so that the gradient reaching the deep stages is not a sum of cancelling noise terms.  fp32 and
+    float64 runs of the reference's own class bodies; every parameter's strided gradient sample + norm."""
+    sup = [torch.eye(67)]
+    ns_g = R.load_gwnet(False, sup)
+    ns = R.load_unet(ns_g['gwnet'], image_dimension=size)
+    schema = P.unet_schema(input_channels=channels, output_channels=channels, image_dimension=size)
+    x = rand(seed + 1, (1, 67, H, channels, size, size))
+    tdim = rand(seed + 3, (1, 67, H, 64))
+    tgt = 0.5 * x
+    d = dict(seed=np.int64(seed))
+    for tag, dt in (('', torch.float32), ('64', torch.float64)):
+        m = _unet_model(ns, schema, seed, H, channels, dt)
+        y = m(x.to(dt), tdim.to(dt))
+        loss = F.mse_loss(y, tgt.to(dt))
+        loss.backward()
+        d['loss' + tag] = np.float64(loss.item())
+        if not tag:
+            yn = y.detach().numpy()
+            d['y_sample'] = yn.reshape(-1)[::997].copy()
+            d.update(grad_summary(m, max_full=1100))
+        else:
+            for k, prm in m.named_parameters():
+                if prm.grad is None:
+                    continue
+                g = prm.grad.detach().numpy()
+                d['gnorm64/' + k] = np.float64(np.sqrt((g ** 2).sum()))
+                if g.size <= 1100:
+                    d['grad64/' + k] = g
+                else:
+                    d['gsample64/' + k] = g.reshape(-1)[::max(1, g.size // 2048)][:2048].copy()
+        print(name, tag or '32', 'loss', loss.item(), flush=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+
+
 def checkpoint_case(name='gwnet_ckpt', seed=1234):
     """A Lightning-shaped checkpoint of the reference's own gwnet class (lit.py:59-72,187-196): default-initialised
     under torch.manual_seed (so the init values pin the constructor's RNG consumption order), trained 3 steps with
@@ -368,6 +488,16 @@ if __name__ == '__main__':
         date2vec_case()
     if 'unet' in which:
         modified_unet_case('modified_unet_B2H2', B=2, H=2, seed=400)
+    if 'traj_gwnet' in which:
+        A300 = P.knn_graph(300, seed=2)
+        gwnet_trajectory_case('traj_gwnet_C2s', B=4, N=300, T=12, in_dim=32, out_dim=12, K=2,
+                              static_supports=[asym_adj(A300), asym_adj(A300.T)], seed=600)
+    if 'traj_unet' in which:
+        unet_trajectory_case('traj_unet_B1H2', B=1, H=2, seed=610)
+    if 'traj_unet_c3' in which:
+        unet_trajectory_case('traj_unet_C3', B=1, H=2, seed=620, channels=13, size=256, with_f64=False)
+    if 'unet_h7' in which:
+        unet_conditioned_grad_case()
     if 'unet_c3' in which:
         # BASELINE config 3: 13-channel 256x256 tiles (FC bottleneck 16384 -> 4096 -> 256 -> 1024 -> 16384)
         modified_unet_case('modified_unet_C3', B=1, H=2, seed=410, channels=13, size=256)
