@@ -211,6 +211,36 @@ long mo_colsum_ws_floats(long P, int C);
 int mo_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                  float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, void* stream);
 
+/* ==== Small-graph Graph WaveNet body (csrc/gwnet_small.hip) ==========================================
+ * The whole layer stack of graph_wavenet.py:214-250 (gated TCN with kernel_size 1 -> diffusion hops -> mlp + dropout +
+ * residual -> BatchNorm statistics) of ONE forward call of a SMALL graph in ONE workgroup; all B calls of a step in one
+ * launch, BatchNorm statistics per call -- the reference calls the network once per batch element (unet.py:221), each
+ * call a batch of one window, so its train-mode BatchNorm2d sees (1, N, T).  Rows are nbtc with B = number of calls, so
+ * mo_nchw_to_nbtc / mo_conv1x1_* / mo_nbtc_to_nchw serve the start conv, the skip contraction and the head around it.
+ *   dense_of[k] (k < nsup, supports in the reference's order, the adaptive one last): -1 = the identity matrix (folded
+ *     into the mlp weights), else the index d of its dense N x N matrix adj[d] (d counts up from 0 in support order)
+ *   params: L x {Wf, bf, Wg, bg, Wmlp, bmlp, gamma, beta, running_mean, running_var} device pointers
+ *   gcat [rows][32 L] (the gated outputs of all layers side by side), hs [L][rows][32], xs [L][ndense][2][rows][32],
+ *   stats [B][L][6][32] (scale, shift, mean, rstd, unbiased variance, unused) are outputs = saved for backward.
+ *   training: batch statistics + the B sequential running-statistic updates (momentum); else running statistics.
+ * Limits: mo_gwnet_small_supported (L <= 16, <= 3 supports, N <= 80, N*T <= 8192, LDS). */
+int mo_gwnet_small_supported(int N, int T, int L, int nsup, int ndense);
+int mo_gwnet_small_fwd(int B, int N, int T, int L, int nsup, const int* dense_of, const float* const* adj,
+                       const void* const* params, const float* h0, float* gcat, float* hs, float* xs, float* stats,
+                       int training, float eps, float momentum, uint32_t seed, uint32_t thresh, float dscale,
+                       void* stream);
+/* backward of the same stack.  dgskip [rows][32 L]: gradient reaching every g_i through the skip path; dxo [rows][32]:
+ * OUT, gradient w.r.t. h0; dsts: L x {dWf, dbf, dWg, dbg, dWmlp, dbmlp, dgamma, dbeta} destinations (NULL = not wanted),
+ * written as the fixed-order sum over the calls; adaptive_dense: dense index whose gradient dA [N][N] is wanted, or -1;
+ * ws: mo_gwnet_small_bwd_ws_floats. */
+long mo_gwnet_small_bwd_ws_floats(int B, int N, int T, int L, int nsup, int ndense);
+long mo_gwnet_small_slab_floats(int nsup);
+int mo_gwnet_small_bwd(int B, int N, int T, int L, int nsup, const int* dense_of, const float* const* adj,
+                       int adaptive_dense, const void* const* params, void* const* dsts, const float* h0,
+                       const float* gcat, const float* hs, const float* xs, const float* stats, float eps,
+                       uint32_t seed, uint32_t thresh, float dscale, const float* dgskip, float* dxo, float* ws,
+                       float* dA, void* stream);
+
 /* ==== UNet encoder/decoder conv stacks (unet.py:40-92, batched over all B*67*H tiles) ===============
  * NCHW images; `istride`/`ostride` are image strides in floats (so channel slices of wider buffers can
  * be addressed).  An "activated view" is a raw conv output y with the folded per-(group,channel)

@@ -64,6 +64,13 @@ SIGNATURES = {
     'mo_colsum': (i32, [vp, i64, i32, vp, vp, vp]),
     'mo_colsum_ws_floats': (i64, [i64, i32]),
     'mo_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, vp]),
+    # ---- small-graph Graph WaveNet body (one workgroup per call)
+    'mo_gwnet_small_supported': (i32, [i32, i32, i32, i32, i32]),
+    'mo_gwnet_small_fwd': (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u32, u32, f32, vp]),
+    'mo_gwnet_small_bwd_ws_floats': (i64, [i32, i32, i32, i32, i32, i32]),
+    'mo_gwnet_small_slab_floats': (i64, [i32]),
+    'mo_gwnet_small_bwd': (i32, [i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, u32, u32, f32,
+                                 vp, vp, vp, vp, vp]),
     # ---- UNet
     'mo_conv3x3_fwd': (i32, [vp, i32, i64, vp, vp, i32, vp, i32, i64, vp, vp, i32, i32, vp, i32, i64, i32, i32,
                              vp, i64, vp, i32, vp, vp]),

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '_build')
 LIB = os.path.join(HERE, 'libmo_hip.so')
-SOURCES = ['gwnet_ops.hip', 'unet_ops.hip', 'gemm_bf16.hip', 'comm.hip']   # comm.hip is what needs -lrccl
+SOURCES = ['gwnet_ops.hip', 'unet_ops.hip', 'gemm_bf16.hip', 'gwnet_small.hip', 'comm.hip']   # comm.hip is what needs -lrccl
 _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 
 

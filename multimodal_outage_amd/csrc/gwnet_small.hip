@@ -1,0 +1,764 @@
+// Small-graph Graph WaveNet body for gfx950: the whole stack of layers (gated TCN -> diffusion hops -> mlp + dropout +
+// residual -> BatchNorm statistics, graph_wavenet.py:214-250) of ONE forward call in ONE workgroup, forward and backward.
+//
+// Why: inside Modified_UNET the Graph WaveNet runs on the 67-county graph, one call per batch element
+// (unet.py:221), each call a batch of ONE window with kernel_size 1: an activation is N*T*32 floats = 17 KB (H = 2) ..
+// 60 KB (H = 7).  The general engine spends ~25 launches of 3..20 us per layer on it (300 per call, 1.7 ms of GPU time
+// and 3 ms of launch-thread time per window, profiles/r02_unet_c3_kernel_stats.csv) -- the work itself is 37 MFLOP.
+// Here a call is one workgroup of 16 waves: every contraction of a layer is cut into 16x16 tiles that the waves take in
+// turn (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation), the weights of the layer and the dense supports
+// sit in LDS, activations live in the saved-for-backward tensors (L1/L2 resident, written once), phases are separated
+// by workgroup barriers.  All B calls of a step are one launch (grid = B); BatchNorm statistics are per call -- exactly
+// the (1, N, T) statistics of the reference's per-call BatchNorm2d (unet.py:221 -> graph_wavenet.py:250).
+//
+// Layout: the engine's "nbtc" rows r = (n*B + b)*T + t of 32 channels (include/mo_hip.h), so the start conv, the skip
+// contraction, the head and the boundary transposes of the general engine are used unchanged around this kernel.
+// Supports: the identity (the reference's default static support, graph_wavenet.py:13-32) is folded into the mlp
+// weights of the layer (x1 = x2 = g); every other support, static or adaptive, is a dense N x N matrix in LDS.
+#include "mo_common.h"
+#include "../../include/mo_hip.h"
+
+typedef float sg_f4 __attribute__((ext_vector_type(4)));
+#define SG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define SG_MAXL 16
+#define SG_MAXS 3
+#define SG_THREADS 1024
+#define SG_WAVES 16
+#define SG_LDW 66          // LDS row stride of a [k][64] weight image: % 4 == 2 -> the four k-groups of a wave hit disjoint banks
+#define SG_LDM 34          // ... of a [k][32] image
+
+struct SgLayer {
+  const float *Wf, *bf, *Wg, *bg;     // (32,32), (32)
+  const float *Wm, *bm;               // (32, 32*(1+2S)), (32): reference column order [g, A1 g, A1^2 g, A2 g, ...]
+  const float *gamma, *beta;          // BatchNorm affine
+  float *rmean, *rvar;                // running statistics (eval mode reads them; training: sg_running_kernel)
+};
+struct SgArgs {
+  int B, N, T, L, P;                  // calls, nodes, steps, layers, P = N*T positions per call
+  int nsup, ndense;                   // supports in reference order; ndense of them are dense matrices
+  int dense_of[SG_MAXS];              // support k -> index of its dense matrix, or -1 (identity)
+  const float* adj[SG_MAXS];          // dense supports A_d [N][N] row-major (nconv applies A^T on the node axis)
+  int adaptive_dense;                 // index of the adaptive support among the dense ones (its gradient is wanted), or -1
+  SgLayer ly[SG_MAXL];
+  const float* h0;                    // [rows][32] start-conv output
+  float* gcat;                        // [rows][32 L]: gated TCN outputs of all layers side by side (the skip contraction's operand)
+  float* hs;                          // [L][rows][32] pre-BatchNorm layer outputs
+  float* xs;                          // [L][ndense][2][rows][32] diffusion hops x1, x2
+  float* stats;                       // [B][L][6][32]: scale, shift, mean, rstd, unbiased variance, (unused)
+  int training; float eps;
+  uint32_t seed; uint32_t thresh; float dscale;     // dropout (seed of layer i: seed + 7919 i), 0 = off
+  // backward only
+  const float* dgskip;                // [rows][32 L]: d loss / d g_i through the skip path
+  float* dxo;                         // [rows][32] gradient w.r.t. a layer's output (in: none; out: gradient w.r.t. h0)
+  float* dh;                          // [rows][32] scratch: gradient w.r.t. the pre-BatchNorm output
+  float* dg;                          // [rows][32] scratch
+  float* dxs;                         // [ndense][2][rows][32] scratch: gradients of the hops
+  float* dpre;                        // [rows][64] scratch: gradients of the TCN pre-activations
+  float* slab;                        // [B][L][SG_SLAB]: per-call parameter gradients
+  float* dA;                          // [B][N][N] per-call gradient of the adaptive support (or null)
+  long rows;                          // N*B*T
+};
+// per-layer slab layout (floats)
+#define SG_S_WF 0
+#define SG_S_BF 1024
+#define SG_S_WG 1056
+#define SG_S_BG 2080
+#define SG_S_BM 2112
+#define SG_S_GA 2144
+#define SG_S_BE 2176
+#define SG_S_WM 2208                 // 32 * 32 * (1 + 2 * nsup) follow
+static inline long sg_slab_floats(int nsup) { return SG_S_WM + 32L * 32 * (1 + 2 * nsup); }
+
+__device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sg_tanh(float x) { return tanhf(x); }
+
+// One 16x16 output tile: acc += A_op[16][32 kc .. 32 kc + 31] * B_op[..][16] for kc in [0, kchunks); the loaders fill
+// a[j] = A_op[m0 + lane%16][32 kc + 8 q + j], b[j] = B_op[32 kc + 8 q + j][n0 + lane%16] (q = lane / 16): the MFMA's four
+// k slots of a step are the four q groups, so a lane's eight k are CONTIGUOUS in memory for a k-major operand.
+template <class LA, class LB>
+__device__ __forceinline__ sg_f4 sg_tile(int kchunks, LA la, LB lb) {
+  sg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < kchunks; ++kc) {
+    float a[8], b[8];
+    la(kc, a); lb(kc, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = SG_MFMA(a[j], b[j], acc);
+  }
+  return acc;
+}
+
+struct SgGeo {
+  int B, T, P, N, b;
+  __device__ __forceinline__ long row(int pl) const { const int n = pl / T; return (long)pl + (long)n * (B - 1) * T + (long)b * T; }
+  __device__ __forceinline__ long nrow(int n, int t) const { return ((long)n * B + b) * T + t; }
+};
+
+__device__ __forceinline__ void sg_ld8(const float* p, float* a) {
+  const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + 4);
+  a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w; a[4] = v.x; a[5] = v.y; a[6] = v.z; a[7] = v.w;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// dynamic LDS: adj [ndense][N][LDA] | wt [32][SG_LDW] (filter|gate, k-major) | wm [32 ne][SG_LDM] (k-major) | biases etc.
+__global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+  const int N = a.N, T = a.T, P = a.P, J = T * 32, LDA = N + 3 - ((N + 1) & 3);
+  // LDA % 4 == 2 (bank spread of the four k groups): N + 3 - ((N + 1) & 3) is the smallest value >= N that is 2 (mod 4)
+  const int ne = 1 + 2 * a.ndense;
+  float* adj_s = lds;
+  float* wt = adj_s + a.ndense * N * LDA;
+  float* wm = wt + 32 * SG_LDW;
+  float* bias = wm + 32 * ne * SG_LDM;          // bf[32] bg[32] bm[32]
+  float* aff = bias + 96;                        // scale[32] shift[32] of the layer input
+  float* part = aff + 64;                        // [SG_WAVES][64] BatchNorm partial sums
+  SgGeo g; g.B = a.B; g.T = T; g.P = P; g.N = N; g.b = blockIdx.x;
+  const long rows = a.rows;
+  const int ldg = 32 * a.L;
+  for (int d = 0; d < a.ndense; ++d)
+    for (int i = tid; i < N * N; i += SG_THREADS) adj_s[(d * N + i / N) * LDA + i % N] = a.adj[d][i];
+  const int mtiles = (P + 15) >> 4;
+
+  for (int li = 0; li < a.L; ++li) {
+    const SgLayer& Ly = a.ly[li];
+    // ---- weights of the layer into LDS (k-major images); identity supports folded into the g block of the mlp
+    for (int i = tid; i < 32 * 32; i += SG_THREADS) {
+      const int co = i >> 5, ci = i & 31;
+      wt[ci * SG_LDW + co] = Ly.Wf[i];
+      wt[ci * SG_LDW + 32 + co] = Ly.Wg[i];
+      const float* wrow = Ly.Wm + (long)co * 32 * (1 + 2 * a.nsup);
+      float w0 = wrow[ci];
+      for (int k = 0; k < a.nsup; ++k) {
+        const int d = a.dense_of[k];
+        const float w1 = wrow[32 * (1 + 2 * k) + ci], w2 = wrow[32 * (2 + 2 * k) + ci];
+        if (d < 0) w0 += w1 + w2;
+        else { wm[(32 * (1 + 2 * d) + ci) * SG_LDM + co] = w1; wm[(32 * (2 + 2 * d) + ci) * SG_LDM + co] = w2; }
+      }
+      wm[ci * SG_LDM + co] = w0;
+    }
+    if (tid < 32) { bias[tid] = Ly.bf[tid]; bias[32 + tid] = Ly.bg[tid]; bias[64 + tid] = Ly.bm[tid]; }
+    if (li == 0 && tid < 32) { aff[tid] = 1.f; aff[32 + tid] = 0.f; }
+    __syncthreads();
+    const float* xin = li == 0 ? a.h0 : a.hs + (long)(li - 1) * rows * 32;
+    float* gout = a.gcat + li * 32;
+
+    // ---- A: gated TCN (kernel_size 1: two 1x1 convs)  g = tanh(Wf x + bf) * sigmoid(Wg x + bg)
+    for (int job = wave; job < mtiles * 2; job += SG_WAVES) {
+      const int mt = job >> 1, nh = job & 1;
+      const int pl = min(mt * 16 + l16, P - 1);
+      const float* xr = xin + g.row(pl) * 32 + 8 * q;
+      float av[8];
+      sg_ld8(xr, av);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = av[j] * aff[8 * q + j] + aff[32 + 8 * q + j];
+      sg_f4 af = {0.f, 0.f, 0.f, 0.f}, ag = af;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        af = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + nh * 16 + l16], af);
+        ag = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + 32 + nh * 16 + l16], ag);
+      }
+      const int c = nh * 16 + l16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int po = mt * 16 + 4 * q + i;
+        if (po < P) gout[g.row(po) * ldg + c] = sg_tanh(af[i] + bias[c]) * sg_sigmoid(ag[i] + bias[32 + c]);
+      }
+    }
+    __syncthreads();
+
+    // ---- B: diffusion hops of the dense supports: x1 = A^T g, x2 = A^T x1 on the node axis ([N][T*32] matrices)
+    for (int hop = 0; hop < 2 && a.ndense > 0; ++hop) {
+      const int ntn = (N + 15) >> 4, ntj = J >> 4, kch = (N + 31) >> 5;
+      for (int job = wave; job < a.ndense * ntn * ntj; job += SG_WAVES) {
+        const int d = job / (ntn * ntj), r2 = job - d * (ntn * ntj), mt = r2 / ntj, nt = r2 - mt * ntj;
+        const float* As = adj_s + d * N * LDA;
+        float* x1 = a.xs + (((long)li * a.ndense + d) * 2) * rows * 32;
+        const float* src = hop == 0 ? gout : x1;
+        const int lds_ = hop == 0 ? ldg : 32;
+        float* dst = hop == 0 ? x1 : x1 + rows * 32;
+        const int wcl = min(mt * 16 + l16, N - 1);
+        const int jc = nt * 16 + l16, tt = jc >> 5, cc = jc & 31;
+        sg_f4 acc = sg_tile(kch,
+            [&](int kc, float* av) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { const int v = kc * 32 + 8 * q + j; av[j] = v < N ? As[v * LDA + wcl] : 0.f; }
+            },
+            [&](int kc, float* bv) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { const int v = min(kc * 32 + 8 * q + j, N - 1); bv[j] = src[g.nrow(v, tt) * lds_ + cc]; }
+            });
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int w = mt * 16 + 4 * q + i;
+          if (w < N) dst[g.nrow(w, tt) * 32 + cc] = acc[i];
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- C: mlp over [g, x1_d, x2_d ...] + bias, dropout, residual; BatchNorm partial sums
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float* hout = a.hs + (long)li * rows * 32;
+    const uint32_t lseed = a.seed + 7919u * (uint32_t)li;
+    for (int job = wave; job < mtiles * 2; job += SG_WAVES) {
+      const int mt = job >> 1, nh = job & 1;
+      const int pl = min(mt * 16 + l16, P - 1);
+      const long r = g.row(pl);
+      sg_f4 acc = sg_tile(ne,
+          [&](int e, float* av) {
+            const float* s = e == 0 ? gout + r * ldg : a.xs + (((long)li * a.ndense) * 2 + (e - 1)) * rows * 32 + r * 32;
+            sg_ld8(s + 8 * q, av);
+          },
+          [&](int e, float* bv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[j] = wm[(e * 32 + 8 * q + j) * SG_LDM + nh * 16 + l16];
+          });
+      const int c = nh * 16 + l16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int po = mt * 16 + 4 * q + i;
+        if (po < P) {
+          const long ro = g.row(po);
+          float v = acc[i] + bias[64 + c];
+          if (a.thresh) v = mo_hash32(lseed, (uint32_t)(ro * 32 + c)) < a.thresh ? 0.f : v * a.dscale;
+          v += xin[ro * 32 + c] * aff[c] + aff[32 + c];
+          hout[ro * 32 + c] = v;
+          s1[nh] += v; s2[nh] += v * v;
+        }
+      }
+    }
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      float t1 = s1[nh], t2 = s2[nh];
+      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      if (q == 0) { part[wave * 64 + nh * 16 + l16] = t1; part[wave * 64 + 32 + nh * 16 + l16] = t2; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float* st = a.stats + ((long)blockIdx.x * a.L + li) * 6 * 32;
+      float sc, sh;
+      if (a.training) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < SG_WAVES; ++w) { t1 += (double)part[w * 64 + tid]; t2 += (double)part[w * 64 + 32 + tid]; }
+        const double mean = t1 / P;
+        double var = t2 / P - mean * mean; if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        sc = Ly.gamma[tid] * rstd; sh = Ly.beta[tid] - (float)mean * sc;
+        st[64 + tid] = (float)mean; st[96 + tid] = rstd; st[128 + tid] = (float)(P > 1 ? var * P / (P - 1) : var);
+      } else {
+        const float rstd = 1.f / sqrtf(Ly.rvar[tid] + a.eps);
+        sc = Ly.gamma[tid] * rstd; sh = Ly.beta[tid] - Ly.rmean[tid] * sc;
+        st[64 + tid] = Ly.rmean[tid]; st[96 + tid] = rstd; st[128 + tid] = Ly.rvar[tid];
+      }
+      st[tid] = sc; st[32 + tid] = sh;
+      aff[tid] = sc; aff[32 + tid] = sh;
+    }
+    __syncthreads();
+  }
+}
+
+// running statistics: the B calls of a step update them one after the other (unet.py:221), momentum 0.1
+__global__ void sg_running_kernel(SgArgs a, float momentum) {
+  const int li = blockIdx.x, c = threadIdx.x;
+  if (c >= 32) return;
+  float rm = a.ly[li].rmean[c], rv = a.ly[li].rvar[c];
+  for (int b = 0; b < a.B; ++b) {
+    const float* st = a.stats + ((long)b * a.L + li) * 6 * 32;
+    rm = (1.f - momentum) * rm + momentum * st[64 + c];
+    rv = (1.f - momentum) * rv + momentum * st[128 + c];
+  }
+  a.ly[li].rmean[c] = rm; a.ly[li].rvar[c] = rv;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dynamic LDS: adj | wt (k-major filter|gate, for the recompute) | wtn [64][SG_LDM] natural (data gradient of the TCN)
+//            | wmn [32][32 ne + 2] natural (data gradient of the mlp) | bias | aff | small reduction scratch
+__global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+  const int N = a.N, T = a.T, P = a.P, J = T * 32, LDA = N + 3 - ((N + 1) & 3);
+  const int ne = 1 + 2 * a.ndense, LDN = 32 * ne + 2;
+  float* adj_s = lds;
+  float* wt = adj_s + a.ndense * N * LDA;
+  float* wtn = wt + 32 * SG_LDW;
+  float* wmn = wtn + 64 * SG_LDM;
+  float* bias = wmn + 32 * LDN;                 // bf | bg
+  float* aff = bias + 64;                        // scale, shift of the layer input
+  float* bnk = aff + 64;                         // gamma*rstd [32], k1 [32], k2 [32], mean [32], rstd [32]
+  double* red = reinterpret_cast<double*>(bnk + 160);    // [32][33] x 3 doubles ... sized below
+  SgGeo g; g.B = a.B; g.T = T; g.P = P; g.N = N; g.b = blockIdx.x;
+  const long rows = a.rows;
+  const int ldg = 32 * a.L;
+  const long slabL = SG_S_WM + 32L * 32 * (1 + 2 * a.nsup);
+  for (int d = 0; d < a.ndense; ++d)
+    for (int i = tid; i < N * N; i += SG_THREADS) adj_s[(d * N + i / N) * LDA + i % N] = a.adj[d][i];
+  const int mtiles = (P + 15) >> 4;
+  const int ntn = (N + 15) >> 4;
+  // persistent accumulators of the adaptive support's gradient: tile (mt, nt) of dA[v][w] owned by a fixed wave
+  sg_f4 accA[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int nAt = (a.adaptive_dense >= 0 && a.dA) ? ntn * ntn : 0;
+
+  for (int li = a.L - 1; li >= 0; --li) {
+    const SgLayer& Ly = a.ly[li];
+    float* slab = a.slab + ((long)blockIdx.x * a.L + li) * slabL;
+    const bool has_dh = li < a.L - 1;            // the last layer's gcn / bn output is dead (graph_wavenet.py:252)
+    // ---- weights
+    for (int i = tid; i < 32 * 32; i += SG_THREADS) {
+      const int co = i >> 5, ci = i & 31;
+      wt[ci * SG_LDW + co] = Ly.Wf[i]; wt[ci * SG_LDW + 32 + co] = Ly.Wg[i];
+      wtn[co * SG_LDM + ci] = Ly.Wf[i]; wtn[(32 + co) * SG_LDM + ci] = Ly.Wg[i];
+      const float* wrow = Ly.Wm + (long)co * 32 * (1 + 2 * a.nsup);
+      float w0 = wrow[ci];
+      for (int k = 0; k < a.nsup; ++k) {
+        const int d = a.dense_of[k];
+        const float w1 = wrow[32 * (1 + 2 * k) + ci], w2 = wrow[32 * (2 + 2 * k) + ci];
+        if (d < 0) w0 += w1 + w2;
+        else { wmn[co * LDN + 32 * (1 + 2 * d) + ci] = w1; wmn[co * LDN + 32 * (2 + 2 * d) + ci] = w2; }
+      }
+      wmn[co * LDN + ci] = w0;
+    }
+    if (tid < 32) {
+      bias[tid] = Ly.bf[tid]; bias[32 + tid] = Ly.bg[tid];
+      if (li == 0) { aff[tid] = 1.f; aff[32 + tid] = 0.f; }
+      else { const float* sp = a.stats + ((long)blockIdx.x * a.L + li - 1) * 6 * 32; aff[tid] = sp[tid]; aff[32 + tid] = sp[32 + tid]; }
+      const float* st = a.stats + ((long)blockIdx.x * a.L + li) * 6 * 32;
+      bnk[96 + tid] = st[64 + tid]; bnk[128 + tid] = st[96 + tid];
+    }
+    __syncthreads();
+    const float* xin = li == 0 ? a.h0 : a.hs + (long)(li - 1) * rows * 32;
+    const float* gl = a.gcat + li * 32;
+    const float* hl = a.hs + (long)li * rows * 32;
+    const uint32_t lseed = a.seed + 7919u * (uint32_t)li;
+    const int tr = tid >> 5, tc = tid & 31;       // elementwise phases: 32 rows x 32 channels per sweep
+
+    if (has_dh) {
+      // ---- R1: BatchNorm backward sums  s1 = sum dxo, s2 = sum dxo * xhat   (per channel over the call's P positions)
+      {
+        double s1 = 0.0, s2 = 0.0;
+        const float mu = bnk[96 + tc], rs = bnk[128 + tc];
+        for (int pl = tr; pl < P; pl += 32) {
+          const long r = g.row(pl);
+          const float d = a.dxo[r * 32 + tc];
+          s1 += (double)d; s2 += (double)d * (double)((hl[r * 32 + tc] - mu) * rs);
+        }
+        red[tr * 33 + tc] = s1; red[32 * 33 + tr * 33 + tc] = s2;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < 32; ++k) { s1 += red[k * 33 + tid]; s2 += red[32 * 33 + k * 33 + tid]; }
+        slab[SG_S_GA + tid] = (float)s2; slab[SG_S_BE + tid] = (float)s1;
+        bnk[tid] = Ly.gamma[tid] * bnk[128 + tid];
+        bnk[32 + tid] = (float)(s1 / P); bnk[64 + tid] = (float)(s2 / P);
+      }
+      __syncthreads();
+      // ---- R2: dh = gamma rstd (dxo - k1 - xhat k2); bias gradient of the mlp = sum of the dropout-masked dh
+      {
+        double s3 = 0.0;
+        const float mu = bnk[96 + tc], rs = bnk[128 + tc], gr = bnk[tc], k1 = bnk[32 + tc], k2 = bnk[64 + tc];
+        for (int pl = tr; pl < P; pl += 32) {
+          const long r = g.row(pl);
+          const float v = gr * (a.dxo[r * 32 + tc] - k1 - (hl[r * 32 + tc] - mu) * rs * k2);
+          a.dh[r * 32 + tc] = v;
+          float m = v;
+          if (a.thresh) m = mo_hash32(lseed, (uint32_t)(r * 32 + tc)) < a.thresh ? 0.f : v * a.dscale;
+          s3 += (double)m;
+        }
+        red[tr * 33 + tc] = s3;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        double s3 = 0.0;
+        for (int k = 0; k < 32; ++k) s3 += red[k * 33 + tid];
+        slab[SG_S_BM + tid] = (float)s3;
+      }
+      // ---- M: mlp backward.  data: dsrc_e = dhm @ Wm_eff[:, e]  (e = 0: dg = ... + skip-path gradient);
+      //      weights: dWm[co][e*32 + ci] = sum_p dhm[p][co] src_e[p][ci]
+      const int njd = mtiles * 2 * ne, njw = 2 * 2 * ne;
+      for (int job = wave; job < njd + njw; job += SG_WAVES) {
+        if (job < njd) {
+          const int mt = job / (2 * ne), nt = job - mt * (2 * ne);       // nt: 16-column tile of the 32 ne outputs
+          const int pl = min(mt * 16 + l16, P - 1);
+          const long r = g.row(pl);
+          float av[8];
+          sg_ld8(a.dh + r * 32 + 8 * q, av);
+          if (a.thresh) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = mo_hash32(lseed, (uint32_t)(r * 32 + 8 * q + j)) < a.thresh ? 0.f : av[j] * a.dscale;
+          }
+          sg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = SG_MFMA(av[j], wmn[(8 * q + j) * LDN + nt * 16 + l16], acc);
+          const int e = nt >> 1, c = (nt & 1) * 16 + l16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int po = mt * 16 + 4 * q + i;
+            if (po < P) {
+              const long ro = g.row(po);
+              if (e == 0) a.dg[ro * 32 + c] = acc[i] + a.dgskip[ro * ldg + li * 32 + c];
+              else a.dxs[(long)(e - 1) * rows * 32 + ro * 32 + c] = acc[i];
+            }
+          }
+        } else {
+          const int jw = job - njd, ct = jw / (2 * ne), nt = jw - ct * (2 * ne);
+          const int e = nt >> 1, ci = (nt & 1) * 16 + l16, co = ct * 16 + l16;
+          const float* s = e == 0 ? gl : a.xs + (((long)li * a.ndense) * 2 + (e - 1)) * rows * 32;
+          const int lds_ = e == 0 ? ldg : 32;
+          sg_f4 acc = sg_tile((P + 31) >> 5,
+              [&](int kc, float* av) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int pl = kc * 32 + 8 * q + j;
+                  float v = 0.f;
+                  if (pl < P) {
+                    const long r = g.row(pl);
+                    v = a.dh[r * 32 + co];
+                    if (a.thresh) v = mo_hash32(lseed, (uint32_t)(r * 32 + co)) < a.thresh ? 0.f : v * a.dscale;
+                  }
+                  av[j] = v;
+                }
+              },
+              [&](int kc, float* bv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int pl = min(kc * 32 + 8 * q + j, P - 1); bv[j] = s[g.row(pl) * lds_ + ci]; }
+              });
+          // rows co = ct*16 + 4q + i, column e*32 + (nt&1)*16 + l16; the g block also is the gradient of every identity block
+          const int W = 32 * (1 + 2 * a.nsup);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* drow = slab + SG_S_WM + (long)(ct * 16 + 4 * q + i) * W;
+            if (e == 0) {
+              drow[ci] = acc[i];
+              for (int k = 0; k < a.nsup; ++k)
+                if (a.dense_of[k] < 0) { drow[32 * (1 + 2 * k) + ci] = acc[i]; drow[32 * (2 + 2 * k) + ci] = acc[i]; }
+            } else {
+              int k = 0;
+              for (; k < a.nsup; ++k) if (a.dense_of[k] == ((e - 1) >> 1)) break;
+              drow[32 * (1 + 2 * k + ((e - 1) & 1)) + ci] = acc[i];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- N1: dx1_d += A_d dx2_d
+      if (a.ndense > 0) {
+        const int ntj = J >> 4, kch = (N + 31) >> 5;
+        for (int job = wave; job < a.ndense * ntn * ntj; job += SG_WAVES) {
+          const int d = job / (ntn * ntj), r2 = job - d * (ntn * ntj), mt = r2 / ntj, nt = r2 - mt * ntj;
+          const float* As = adj_s + d * N * LDA;
+          float* dx1 = a.dxs + (long)(2 * d) * rows * 32;
+          const float* dx2 = dx1 + rows * 32;
+          const int vcl = min(mt * 16 + l16, N - 1);
+          const int jc = nt * 16 + l16, tt = jc >> 5, cc = jc & 31;
+          sg_f4 acc = sg_tile(kch,
+              [&](int kc, float* av) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int w = kc * 32 + 8 * q + j; av[j] = w < N ? As[vcl * LDA + w] : 0.f; }
+              },
+              [&](int kc, float* bv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int w = min(kc * 32 + 8 * q + j, N - 1); bv[j] = dx2[g.nrow(w, tt) * 32 + cc]; }
+              });
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int v = mt * 16 + 4 * q + i;
+            if (v < N) dx1[g.nrow(v, tt) * 32 + cc] += acc[i];
+          }
+        }
+        __syncthreads();
+        // ---- N2: dg += sum_d A_d dx1_d ;  dA += x1^T-products of the adaptive support
+        const int njg = ntn * ntj;
+        for (int job = wave; job < njg; job += SG_WAVES) {
+          const int mt = job / ntj, nt = job - mt * ntj;
+          const int vcl = min(mt * 16 + l16, N - 1);
+          const int jc = nt * 16 + l16, tt = jc >> 5, cc = jc & 31;
+          sg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int d = 0; d < a.ndense; ++d) {
+            const float* As = adj_s + d * N * LDA;
+            const float* dx1 = a.dxs + (long)(2 * d) * rows * 32;
+            for (int kc = 0; kc < kch; ++kc) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int w = kc * 32 + 8 * q + j;
+                const float av = w < N ? As[vcl * LDA + w] : 0.f;
+                const float bv = dx1[g.nrow(min(w, N - 1), tt) * 32 + cc];
+                acc = SG_MFMA(av, bv, acc);
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int v = mt * 16 + 4 * q + i;
+            if (v < N) a.dg[g.nrow(v, tt) * 32 + cc] += acc[i];
+          }
+        }
+        if (nAt) {
+          const int d = a.adaptive_dense;
+          const float* x1 = a.xs + (((long)li * a.ndense + d) * 2) * rows * 32;
+          const float* dx1 = a.dxs + (long)(2 * d) * rows * 32;
+          const float* dx2 = dx1 + rows * 32;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int job = wave + s * SG_WAVES;
+            if (job < nAt) {
+              const int mt = job / ntn, nt = job - mt * ntn;
+              const int vcl = min(mt * 16 + l16, N - 1), wcl = min(nt * 16 + l16, N - 1);
+              // dA[v][w] += sum_j x1[v][j] dx2[w][j] + g[v][j] dx1[w][j]:  k = j = (t, c), eight contiguous c per lane
+              for (int t = 0; t < T; ++t) {
+                float av[8], bv[8];
+                sg_ld8(x1 + g.nrow(vcl, t) * 32 + 8 * q, av); sg_ld8(dx2 + g.nrow(wcl, t) * 32 + 8 * q, bv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accA[s] = SG_MFMA(av[j], bv[j], accA[s]);
+                sg_ld8(gl + g.nrow(vcl, t) * ldg + 8 * q, av); sg_ld8(dx1 + g.nrow(wcl, t) * 32 + 8 * q, bv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accA[s] = SG_MFMA(av[j], bv[j], accA[s]);
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    } else {
+      // last layer: only the skip path reaches g
+      for (int pl = tr; pl < P; pl += 32) { const long r = g.row(pl); a.dg[r * 32 + tc] = a.dgskip[r * ldg + li * 32 + tc]; }
+      if (tid < 32) { slab[SG_S_GA + tid] = 0.f; slab[SG_S_BE + tid] = 0.f; slab[SG_S_BM + tid] = 0.f; }
+      for (int i = tid; i < 32 * 32 * (1 + 2 * a.nsup); i += SG_THREADS) slab[SG_S_WM + i] = 0.f;
+      __syncthreads();
+    }
+
+    // ---- T1: recompute the pre-activations, form their gradients
+    float sb[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int job = wave; job < mtiles * 2; job += SG_WAVES) {
+      const int mt = job >> 1, nh = job & 1;
+      const int pl = min(mt * 16 + l16, P - 1);
+      float av[8];
+      sg_ld8(xin + g.row(pl) * 32 + 8 * q, av);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = av[j] * aff[8 * q + j] + aff[32 + 8 * q + j];
+      sg_f4 af = {0.f, 0.f, 0.f, 0.f}, ag = af;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        af = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + nh * 16 + l16], af);
+        ag = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + 32 + nh * 16 + l16], ag);
+      }
+      const int c = nh * 16 + l16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int po = mt * 16 + 4 * q + i;
+        if (po < P) {
+          const long ro = g.row(po);
+          const float th = sg_tanh(af[i] + bias[c]), sg = sg_sigmoid(ag[i] + bias[32 + c]);
+          const float dgv = a.dg[ro * 32 + c];
+          const float df = dgv * sg * (1.f - th * th), dgt = dgv * th * sg * (1.f - sg);
+          a.dpre[ro * 64 + c] = df; a.dpre[ro * 64 + 32 + c] = dgt;
+          sb[nh][0] += df; sb[nh][1] += dgt;
+        }
+      }
+    }
+    float* part = reinterpret_cast<float*>(red);           // [SG_WAVES][64]
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      float t1 = sb[nh][0], t2 = sb[nh][1];
+      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      if (q == 0) { part[wave * 64 + nh * 16 + l16] = t1; part[wave * 64 + 32 + nh * 16 + l16] = t2; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double s = 0.0;
+      for (int w = 0; w < SG_WAVES; ++w) s += (double)part[w * 64 + tid];
+      slab[(tid < 32 ? SG_S_BF : SG_S_BG - 32) + tid] = (float)s;
+    }
+    // ---- T2: du = dpre @ [Wf; Wg] (+ dh through the residual) -> gradient w.r.t. the layer input (before its
+    //      BatchNorm affine); weight gradients of the two convs: dW[c][ci] = sum_p dpre[p][c] xin[p][ci]
+    {
+      const int njd = mtiles * 2, njw = 4 * 2;
+      for (int job = wave; job < njd + njw; job += SG_WAVES) {
+        if (job < njd) {
+          const int mt = job >> 1, nh = job & 1;
+          const int pl = min(mt * 16 + l16, P - 1);
+          const long r = g.row(pl);
+          sg_f4 acc = sg_tile(2,
+              [&](int kc, float* av) { sg_ld8(a.dpre + r * 64 + kc * 32 + 8 * q, av); },
+              [&](int kc, float* bv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = wtn[(kc * 32 + 8 * q + j) * SG_LDM + nh * 16 + l16];
+              });
+          const int c = nh * 16 + l16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int po = mt * 16 + 4 * q + i;
+            if (po < P) {
+              const long ro = g.row(po);
+              a.dxo[ro * 32 + c] = acc[i] + (has_dh ? a.dh[ro * 32 + c] : 0.f);
+            }
+          }
+        } else {
+          const int jw = job - njd, ct = jw >> 1, nh = jw & 1;          // rows c of [Wf; Wg] (64), columns ci (32)
+          const int cr = ct * 16 + l16, ci = nh * 16 + l16;
+          sg_f4 acc = sg_tile((P + 31) >> 5,
+              [&](int kc, float* av) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int pl = kc * 32 + 8 * q + j; av[j] = pl < P ? a.dpre[g.row(pl) * 64 + cr] : 0.f; }
+              },
+              [&](int kc, float* bv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int pl = min(kc * 32 + 8 * q + j, P - 1); bv[j] = xin[g.row(pl) * 32 + ci] * aff[ci] + aff[32 + ci]; }
+              });
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = ct * 16 + 4 * q + i;
+            slab[(c < 32 ? SG_S_WF + c * 32 : SG_S_WG + (c - 32) * 32) + ci] = acc[i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // the gradient w.r.t. the layer input x_li = BN_{li-1}(h_{li-1}) is now in dxo: the next iteration's R phases read it
+  }
+  if (nAt) {
+    float* dA = a.dA + (long)blockIdx.x * N * N;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int job = wave + s * SG_WAVES;
+      if (job < nAt) {
+        const int mt = job / ntn, nt = job - mt * ntn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int v = mt * 16 + 4 * q + i, w = nt * 16 + l16;
+          if (v < N && w < N) dA[v * N + w] = accA[s][i];
+        }
+      }
+    }
+  }
+}
+
+// sum of the per-call slabs into the parameter gradients (fixed order over the calls)
+struct SgDst { float *Wf, *bf, *Wg, *bg, *Wm, *bm, *gamma, *beta; };
+struct SgReduceArgs { SgDst d[SG_MAXL]; const float* slab; int B, L, nsup; float* dA; const float* dAs; int NN; };
+__global__ void sg_reduce_kernel(SgReduceArgs a) {
+  const long slabL = SG_S_WM + 32L * 32 * (1 + 2 * a.nsup);
+  if ((int)blockIdx.x == a.L) {                 // the adaptive support's gradient
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < a.NN; i += gridDim.y * blockDim.x) {
+      float s = 0.f;
+      for (int b = 0; b < a.B; ++b) s += a.dAs[(long)b * a.NN + i];
+      a.dA[i] = s;
+    }
+    return;
+  }
+  const int li = blockIdx.x;
+  const SgDst& d = a.d[li];
+  for (long i = blockIdx.y * blockDim.x + threadIdx.x; i < slabL; i += gridDim.y * blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) s += a.slab[((long)b * a.L + li) * slabL + i];
+    float* base; long o;
+    if (i < SG_S_BF) { base = d.Wf; o = i; }
+    else if (i < SG_S_WG) { base = d.bf; o = i - SG_S_BF; }
+    else if (i < SG_S_BG) { base = d.Wg; o = i - SG_S_WG; }
+    else if (i < SG_S_BM) { base = d.bg; o = i - SG_S_BG; }
+    else if (i < SG_S_GA) { base = d.bm; o = i - SG_S_BM; }
+    else if (i < SG_S_BE) { base = d.gamma; o = i - SG_S_GA; }
+    else if (i < SG_S_WM) { base = d.beta; o = i - SG_S_BE; }
+    else { base = d.Wm; o = i - SG_S_WM; }
+    if (base) base[o] = s;                       // (null: a parameter without a gradient buffer)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+static int sg_lda(int N) { return N + 3 - ((N + 1) & 3); }
+static size_t sg_fwd_lds(int N, int ndense) {
+  const int ne = 1 + 2 * ndense;
+  return sizeof(float) * ((size_t)ndense * N * sg_lda(N) + 32 * SG_LDW + 32 * ne * SG_LDM + 96 + 64 + SG_WAVES * 64);
+}
+static size_t sg_bwd_lds(int N, int ndense) {
+  const int ne = 1 + 2 * ndense;
+  return sizeof(float) * ((size_t)ndense * N * sg_lda(N) + 32 * SG_LDW + 64 * SG_LDM + 32 * (32 * ne + 2) + 64 + 64 + 160) +
+         sizeof(double) * (2 * 32 * 33) + 64;
+}
+extern "C" int mo_gwnet_small_supported(int N, int T, int L, int nsup, int ndense) {
+  if (N < 1 || T < 1 || L < 1 || L > SG_MAXL || nsup < 0 || nsup > SG_MAXS || ndense < 0 || ndense > nsup) return 0;
+  if ((long)N * T > 8192 || N > 80) return 0;      // (the adaptive support's gradient: <= 32 tiles of 16 x 16, two per wave)
+  return sg_bwd_lds(N, ndense) <= 160 * 1024 && sg_fwd_lds(N, ndense) <= 160 * 1024;
+}
+extern "C" long mo_gwnet_small_slab_floats(int nsup) { return sg_slab_floats(nsup); }
+
+// params: L * 10 device pointers per layer in SgLayer order; dsts: L * 8 in SgDst order (backward)
+static int sg_fill(SgArgs& a, int B, int N, int T, int L, int nsup, const int* dense_of, const float* const* adj,
+                   int adaptive_dense, const void* const* params) {
+  a.B = B; a.N = N; a.T = T; a.L = L; a.P = N * T; a.nsup = nsup; a.rows = (long)N * B * T;
+  int nd = 0;
+  for (int k = 0; k < SG_MAXS; ++k) { a.dense_of[k] = -1; a.adj[k] = nullptr; }
+  for (int k = 0; k < nsup; ++k) { a.dense_of[k] = dense_of[k]; if (dense_of[k] >= 0) { if (dense_of[k] != nd) return MO_EINVAL; a.adj[nd++] = adj[dense_of[k]]; } }
+  a.ndense = nd; a.adaptive_dense = adaptive_dense;
+  for (int i = 0; i < L; ++i) {
+    const void* const* p = params + (long)i * 10;
+    SgLayer& y = a.ly[i];
+    y.Wf = (const float*)p[0]; y.bf = (const float*)p[1]; y.Wg = (const float*)p[2]; y.bg = (const float*)p[3];
+    y.Wm = (const float*)p[4]; y.bm = (const float*)p[5]; y.gamma = (const float*)p[6]; y.beta = (const float*)p[7];
+    y.rmean = (float*)p[8]; y.rvar = (float*)p[9];
+    for (int k = 0; k < 10; ++k) if (!p[k]) return MO_EINVAL;
+  }
+  return MO_OK;
+}
+extern "C" int mo_gwnet_small_fwd(int B, int N, int T, int L, int nsup, const int* dense_of, const float* const* adj,
+                                  const void* const* params, const float* h0, float* gcat, float* hs, float* xs,
+                                  float* stats, int training, float eps, float momentum, uint32_t seed,
+                                  uint32_t thresh, float dscale, void* stream) {
+  MO_CHECK_ARG(B > 0 && B <= 65535 && dense_of && params && h0 && gcat && hs && stats);
+  SgArgs a = {};
+  int rc = sg_fill(a, B, N, T, L, nsup, dense_of, adj, -1, params);
+  if (rc) return rc;
+  MO_CHECK_ARG(mo_gwnet_small_supported(N, T, L, nsup, a.ndense) && (a.ndense == 0 || xs));
+  a.h0 = h0; a.gcat = gcat; a.hs = hs; a.xs = xs; a.stats = stats; a.training = training; a.eps = eps;
+  a.seed = seed; a.thresh = training ? thresh : 0; a.dscale = dscale;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = sg_fwd_lds(N, a.ndense);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)sg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)sg_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MO_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(sg_fwd_kernel, dim3(B), dim3(SG_THREADS), lds, st, a);
+  if (training) hipLaunchKernelGGL(sg_running_kernel, dim3(L), dim3(32), 0, st, a, momentum);
+  return mo_launch_status();
+}
+extern "C" int mo_gwnet_small_bwd(int B, int N, int T, int L, int nsup, const int* dense_of, const float* const* adj,
+                                  int adaptive_dense, const void* const* params, void* const* dsts, const float* h0,
+                                  const float* gcat, const float* hs, const float* xs, const float* stats, float eps,
+                                  uint32_t seed, uint32_t thresh, float dscale, const float* dgskip, float* dxo,
+                                  float* ws /* mo_gwnet_small_bwd_ws_floats */, float* dA, void* stream) {
+  MO_CHECK_ARG(B > 0 && B <= 65535 && dense_of && params && dsts && h0 && gcat && hs && stats && dgskip && dxo && ws);
+  SgArgs a = {};
+  int rc = sg_fill(a, B, N, T, L, nsup, dense_of, adj, adaptive_dense, params);
+  if (rc) return rc;
+  MO_CHECK_ARG(mo_gwnet_small_supported(N, T, L, nsup, a.ndense) && (a.ndense == 0 || xs));
+  MO_CHECK_ARG(adaptive_dense < a.ndense && (adaptive_dense < 0 || dA));
+  a.h0 = h0; a.gcat = const_cast<float*>(gcat); a.hs = const_cast<float*>(hs); a.xs = const_cast<float*>(xs);
+  a.stats = const_cast<float*>(stats); a.training = 1; a.eps = eps; a.seed = seed; a.thresh = thresh; a.dscale = dscale;
+  a.dgskip = dgskip; a.dxo = dxo;
+  const long R = a.rows * 32;
+  float* w = ws;
+  a.dh = w; w += R; a.dg = w; w += R; a.dxs = w; w += (long)2 * a.ndense * R; a.dpre = w; w += 2 * R;
+  const long slabL = sg_slab_floats(nsup);
+  a.slab = w; w += (long)B * L * slabL;
+  float* dAs = nullptr;
+  if (adaptive_dense >= 0) { dAs = w; w += (long)B * N * N; }
+  a.dA = dAs;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sg_bwd_kernel, dim3(B), dim3(SG_THREADS), sg_bwd_lds(N, a.ndense), st, a);
+  SgReduceArgs r = {};
+  for (int i = 0; i < L; ++i) {
+    void* const* p = dsts + (long)i * 8;
+    r.d[i].Wf = (float*)p[0]; r.d[i].bf = (float*)p[1]; r.d[i].Wg = (float*)p[2]; r.d[i].bg = (float*)p[3];
+    r.d[i].Wm = (float*)p[4]; r.d[i].bm = (float*)p[5]; r.d[i].gamma = (float*)p[6]; r.d[i].beta = (float*)p[7];
+  }
+  r.slab = a.slab; r.B = B; r.L = L; r.nsup = nsup; r.dA = dA; r.dAs = dAs; r.NN = N * N;
+  hipLaunchKernelGGL(sg_reduce_kernel, dim3(L + (dAs ? 1 : 0), 8), dim3(256), 0, st, r);
+  return mo_launch_status();
+}
+extern "C" long mo_gwnet_small_bwd_ws_floats(int B, int N, int T, int L, int nsup, int ndense) {
+  const long R = (long)N * B * T * 32;
+  return R * (4 + 2 * ndense) + (long)B * L * sg_slab_floats(nsup) + (long)B * N * N + 64;
+}

@@ -749,3 +749,210 @@ class GwnetFunction(torch.autograd.Function):
         # gradients written straight into registered flat-buffer views are not handed to autograd
         return (None, None, None, None, None, dx) + tuple(
             None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Small graphs, kernel_size 1, one window per call (the Graph WaveNet inside Modified_UNET, unet.py:221-226): the whole
+# layer stack of a call is ONE workgroup (csrc/gwnet_small.hip), all calls of a step one launch; start conv, skip
+# contraction, head and the boundary transposes are the general engine's kernels around it.
+# ---------------------------------------------------------------------------------------------------------------------
+def small_supported(cfg, n_static, T):
+    lib = L.load()
+    return bool(cfg.K == 1 and cfg.gcn and cfg.L <= 8 and cfg.rf == 1 and
+                lib.mo_gwnet_small_supported(cfg.N, T, cfg.L, n_static + int(cfg.adaptive), n_static + int(cfg.adaptive)))
+
+
+class GwnetSmallFunction(torch.autograd.Function):
+    """y[b] = gwnet_body(x[b]) for every call b of a step, each call a batch of ONE window with its own BatchNorm
+    statistics (graph_wavenet.py:191-254 as Modified_UNET calls it, unet.py:221-226).  x: (B, Cin, N, T) fp32.
+    dense: the static supports as device tensors (N,N) or None for an identity support, in the reference's order."""
+
+    @staticmethod
+    def forward(ctx, cfg, dense, bn_bufs, training, x, *params):
+        p = dict(zip(cfg.names, params))
+        lib = L.load()
+        dev = x.device
+        st = L.stream()
+        B, Cin, N, T = x.shape
+        assert Cin == cfg.Cin and N == cfg.N and cfg.K == 1
+        x = x.contiguous()
+        G = N * B
+        rows = G * T
+        Lc = cfg.L
+        x_int = _e(rows, Cin, dev)
+        L.call('mo_nchw_to_nbtc', L.ptr(x), L.ptr(x_int), B, Cin, N, T, None, st)
+        h0 = _e(rows, 32, dev)
+        L.call('mo_conv1x1_fwd', L.ptr(x_int), Cin, 0, 0, 0, 0, L.ptr(p['start_conv.weight']), L.ptr(p['start_conv.bias']),
+               32, L.ptr(h0), rows, 0, 0, st)
+        adp = None
+        mats = [d for d in dense if d is not None]
+        if cfg.adaptive:
+            adp = _e(N, N, dev)
+            adpT = _e(N, N, dev)
+            L.call('mo_adp_fwd', L.ptr(p['nodevec1']), L.ptr(p['nodevec2']), N, p['nodevec1'].shape[1], L.ptr(adp),
+                   L.ptr(adpT), st)
+            mats = mats + [adp]
+        nsup = len(dense) + int(cfg.adaptive)
+        dense_of, k = [], 0
+        for d in list(dense) + ([adp] if cfg.adaptive else []):
+            dense_of.append(-1 if d is None else k)
+            k += d is not None
+        nd = len(mats)
+        c_dense = (_C.c_int * max(nsup, 1))(*dense_of)
+        c_adj = L.ptr_array(mats) if mats else None
+        plist = []
+        for i in range(Lc):
+            rm, rv = bn_bufs[i]
+            plist += [p[f'filter_convs.{i}.weight'], p[f'filter_convs.{i}.bias'], p[f'gate_convs.{i}.weight'],
+                      p[f'gate_convs.{i}.bias'], p[f'gconv.{i}.mlp.mlp.weight'], p[f'gconv.{i}.mlp.mlp.bias'],
+                      p[f'bn.{i}.weight'], p[f'bn.{i}.bias'], rm, rv]
+        c_params = L.ptr_array(plist)
+        gcat = _e(rows, 32 * Lc, dev)
+        hs = torch.empty((Lc, rows, 32), device=dev, dtype=torch.float32)
+        xs = torch.empty((Lc, max(nd, 1), 2, rows, 32), device=dev, dtype=torch.float32) if nd else None
+        stats = torch.empty((B, Lc, 6, 32), device=dev, dtype=torch.float32)
+        drop_p = cfg.dropout if training else 0.0
+        thresh = int(min(max(drop_p, 0.0), 0.999999) * 4294967296.0) if drop_p > 0 else 0
+        dscale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if thresh else 0
+        L.call('mo_gwnet_small_fwd', B, N, T, Lc, nsup, c_dense, c_adj, c_params, L.ptr(h0), L.ptr(gcat), L.ptr(hs),
+               L.ptr(xs), L.ptr(stats), 1 if training else 0, 1e-5, 0.1, seed, thresh, dscale, st)
+        # skip path: all layers' skip convs are one contraction over the concatenated gated outputs (K = 32 L)
+        Wcat = torch.cat([p[f'skip_convs.{i}.weight'].reshape(cfg.Cs, 32) for i in range(Lc)], dim=1).contiguous()
+        bsum = torch.stack([p[f'skip_convs.{i}.bias'] for i in range(Lc)]).sum(0)
+        skip = _e(rows, cfg.Cs, dev)
+        L.call('mo_conv1x1_fwd', L.ptr(gcat), 32 * Lc, 0, 0, 0, 0, L.ptr(Wcat), L.ptr(bsum), cfg.Cs, L.ptr(skip), rows, 0, 0,
+               st)
+        r1 = _e(rows, cfg.Ce, dev)
+        L.call('mo_conv1x1_fwd', L.ptr(skip), cfg.Cs, 0, 0, 0, 1, L.ptr(p['end_conv_1.weight']), L.ptr(p['end_conv_1.bias']),
+               cfg.Ce, L.ptr(r1), rows, 1, 0, st)
+        y_int = _e(rows, cfg.Cout, dev)
+        L.call('mo_conv1x1_fwd', L.ptr(r1), cfg.Ce, 0, 0, 0, 0, L.ptr(p['end_conv_2.weight']), L.ptr(p['end_conv_2.bias']),
+               cfg.Cout, L.ptr(y_int), rows, 0, 0, st)
+        y = torch.empty((B, cfg.Cout, N, T), device=dev, dtype=torch.float32)
+        L.call('mo_nbtc_to_nchw', L.ptr(y_int), L.ptr(y), B, cfg.Cout, N, T, None, st)
+        ctx.cfg, ctx.training, ctx.params = cfg, training, p
+        ctx.dims = (B, N, T, nsup, nd, dense_of)
+        ctx.keep = (x_int, h0, adp, mats, plist, gcat, hs, xs, stats, skip, r1, Wcat)
+        ctx.drop = (seed, thresh, dscale)
+        ctx.x_needs_grad = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, p = ctx.cfg, ctx.params
+        if not ctx.training:
+            raise RuntimeError('gwnet backward is only defined in training mode (batch-stat BatchNorm)')
+        lib = L.load()
+        B, N, T, nsup, nd, dense_of = ctx.dims
+        x_int, h0, adp, mats, plist, gcat, hs, xs, stats, skip, r1, Wcat = ctx.keep
+        seed, thresh, dscale = ctx.drop
+        dev = dy.device
+        st = L.stream()
+        Lc = cfg.L
+        rows = N * B * T
+        gout = cfg.grad_out or {}
+        grads = {k: None for k in cfg.names}
+
+        def gbuf(name, like=None, shape=None):
+            t = gout.get(name)
+            if t is not None:
+                return t
+            return torch.empty_like(like) if like is not None else torch.empty(shape, device=dev, dtype=torch.float32)
+
+        def ws_for(M, Nn, P):
+            return torch.empty(lib.mo_wgrad_ws_floats(M, Nn, P), device=dev, dtype=torch.float32)
+
+        dy = dy.contiguous()
+        dy_int = _e(rows, cfg.Cout, dev)
+        L.call('mo_nchw_to_nbtc', L.ptr(dy), L.ptr(dy_int), B, cfg.Cout, N, T, None, st)
+        # head (graph_wavenet.py:252-254)
+        gW2 = gbuf('end_conv_2.weight', p['end_conv_2.weight']); gb2 = gbuf('end_conv_2.bias', p['end_conv_2.bias'])
+        L.call('mo_conv1x1_bwd_weight', L.ptr(dy_int), cfg.Cout, rows, L.ptr(r1), cfg.Ce, 0, 0, 0, 0, L.ptr(gW2), L.ptr(gb2),
+               L.ptr(ws_for(cfg.Cout, cfg.Ce, rows)), st)
+        da1 = _e(rows, cfg.Ce, dev)
+        L.call('mo_conv1x1_bwd_data', L.ptr(dy_int), cfg.Cout, rows, L.ptr(p['end_conv_2.weight']), cfg.Ce, L.ptr(da1),
+               0, 0, 0, L.ptr(r1), 0, st)
+        gW1 = gbuf('end_conv_1.weight', p['end_conv_1.weight']); gb1 = gbuf('end_conv_1.bias', p['end_conv_1.bias'])
+        L.call('mo_conv1x1_bwd_weight', L.ptr(da1), cfg.Ce, rows, L.ptr(skip), cfg.Cs, 0, 0, 0, 1, L.ptr(gW1), L.ptr(gb1),
+               L.ptr(ws_for(cfg.Ce, cfg.Cs, rows)), st)
+        dskip = _e(rows, cfg.Cs, dev)
+        L.call('mo_conv1x1_bwd_data', L.ptr(da1), cfg.Ce, rows, L.ptr(p['end_conv_1.weight']), cfg.Cs, L.ptr(dskip),
+               0, 0, 0, L.ptr(skip), 0, st)
+        grads['end_conv_2.weight'], grads['end_conv_2.bias'] = gW2, gb2
+        grads['end_conv_1.weight'], grads['end_conv_1.bias'] = gW1, gb1
+        # skip path: bias gradient (the same for every layer), data gradients of all layers in one product, weight
+        # gradients of all layers in one product over the concatenated gated outputs
+        dbs = torch.empty(cfg.Cs, device=dev, dtype=torch.float32)
+        L.call('mo_colsum', L.ptr(dskip), rows, cfg.Cs, L.ptr(dbs),
+               L.ptr(torch.empty(lib.mo_colsum_ws_floats(rows, cfg.Cs), device=dev, dtype=torch.float32)), st)
+        dgskip = _e(rows, 32 * Lc, dev)
+        L.call('mo_conv1x1_bwd_data', L.ptr(dskip), cfg.Cs, rows, L.ptr(Wcat), 32 * Lc, L.ptr(dgskip), 0, 0, 0, None, 0, st)
+        dWcat = _e(cfg.Cs, 32 * Lc, dev)
+        L.call('mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, rows, L.ptr(gcat), 32 * Lc, 0, 0, 0, 0, L.ptr(dWcat), None,
+               L.ptr(ws_for(cfg.Cs, 32 * Lc, rows)), st)
+        gWs = [gbuf(f'skip_convs.{i}.weight', p[f'skip_convs.{i}.weight']) for i in range(Lc)]
+        L.call('mo_skip_wsplit', L.ptr(dWcat), cfg.Cs, Lc, L.ptr_array(gWs), st)
+        for i in range(Lc):
+            grads[f'skip_convs.{i}.weight'] = gWs[i]
+            sb = gout.get(f'skip_convs.{i}.bias')
+            if sb is not None:
+                sb.copy_(dbs)
+                grads[f'skip_convs.{i}.bias'] = sb
+            else:
+                grads[f'skip_convs.{i}.bias'] = dbs
+        # the layer stack
+        dsts = []
+        for i in range(Lc):
+            last = i == Lc - 1               # the last layer's gcn / bn never reach the output (graph_wavenet.py:252)
+            ds = [gbuf(f'filter_convs.{i}.weight', p[f'filter_convs.{i}.weight']), gbuf(f'filter_convs.{i}.bias', shape=(32,)),
+                  gbuf(f'gate_convs.{i}.weight', p[f'gate_convs.{i}.weight']), gbuf(f'gate_convs.{i}.bias', shape=(32,))]
+            if last:
+                ds += [None, None, None, None]
+            else:
+                ds += [gbuf(f'gconv.{i}.mlp.mlp.weight', p[f'gconv.{i}.mlp.mlp.weight']),
+                       gbuf(f'gconv.{i}.mlp.mlp.bias', shape=(32,)), gbuf(f'bn.{i}.weight', shape=(32,)),
+                       gbuf(f'bn.{i}.bias', shape=(32,))]
+            for key, t in zip((f'filter_convs.{i}.weight', f'filter_convs.{i}.bias', f'gate_convs.{i}.weight',
+                               f'gate_convs.{i}.bias', f'gconv.{i}.mlp.mlp.weight', f'gconv.{i}.mlp.mlp.bias',
+                               f'bn.{i}.weight', f'bn.{i}.bias'), ds):
+                grads[key] = t
+            dsts += ds
+        c_dsts = (_C.c_void_p * len(dsts))(*[None if t is None else t.data_ptr() for t in dsts])
+        c_dense = (_C.c_int * max(nsup, 1))(*dense_of)
+        c_adj = L.ptr_array(mats) if mats else None
+        c_params = L.ptr_array(plist)
+        dh0 = _e(rows, 32, dev)
+        ws = torch.empty(lib.mo_gwnet_small_bwd_ws_floats(B, N, T, Lc, nsup, nd), device=dev, dtype=torch.float32)
+        dAdp = _e(N, N, dev) if cfg.adaptive else None
+        L.call('mo_gwnet_small_bwd', B, N, T, Lc, nsup, c_dense, c_adj, (nd - 1) if cfg.adaptive else -1, c_params, c_dsts,
+               L.ptr(h0), L.ptr(gcat), L.ptr(hs), L.ptr(xs), L.ptr(stats), 1e-5, seed, thresh, dscale, L.ptr(dgskip),
+               L.ptr(dh0), L.ptr(ws), L.ptr(dAdp), st)
+        # start conv (graph_wavenet.py:196)
+        Wst = p['start_conv.weight']
+        gWst = gbuf('start_conv.weight', Wst); gbst = gbuf('start_conv.bias', shape=(32,))
+        L.call('mo_conv1x1_bwd_weight', L.ptr(dh0), 32, rows, L.ptr(x_int), cfg.Cin, 0, 0, 0, 0, L.ptr(gWst), L.ptr(gbst),
+               L.ptr(ws_for(32, cfg.Cin, rows)), st)
+        grads['start_conv.weight'], grads['start_conv.bias'] = gWst, gbst
+        dx = None
+        if ctx.x_needs_grad:
+            dx_int = _e(rows, cfg.Cin, dev)
+            L.call('mo_conv1x1_bwd_data', L.ptr(dh0), 32, rows, L.ptr(Wst), cfg.Cin, L.ptr(dx_int), 0, 0, 0, None, 0, st)
+            dx = torch.empty((B, cfg.Cin, N, T), device=dev, dtype=torch.float32)
+            L.call('mo_nbtc_to_nchw', L.ptr(dx_int), L.ptr(dx), B, cfg.Cin, N, T, None, st)
+        if cfg.adaptive:
+            E1, E2 = p['nodevec1'], p['nodevec2']
+            R = E1.shape[1]
+            gE1 = gbuf('nodevec1', E1); gE2 = gbuf('nodevec2', E2)
+            if Lc > 1:
+                nz = (N + 127) // 128
+                wsa = torch.empty(nz * R * N, device=dev, dtype=torch.float32)
+                L.call('mo_adp_bwd', L.ptr(E1), L.ptr(E2), L.ptr(adp), L.ptr(dAdp), N, R, L.ptr(gE1), L.ptr(gE2), L.ptr(wsa),
+                       wsa.numel(), st)
+            else:
+                gE1.zero_(); gE2.zero_()
+            grads['nodevec1'], grads['nodevec2'] = gE1, gE2
+        if cfg.grad_ready is not None:
+            cfg.grad_ready([n for n in cfg.names if n in gout and gout[n] is not None])
+        return (None, None, None, None, dx) + tuple(
+            None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..gwnet_engine import GwnetConfig, GwnetFunction, StaticSupport
+from ..gwnet_engine import GwnetConfig, GwnetFunction, GwnetSmallFunction, StaticSupport, small_supported
 from ._cache import tree_cache
 
 # Hyperparameters (graph_wavenet.py:37-42)
@@ -232,6 +232,17 @@ class gwnet(nn.Module):
         self.__dict__.pop('_mo_named', None)
         return super()._apply(fn, *a, **kw)
 
+    def _config(self, names):
+        cfg = GwnetConfig(num_nodes=self.num_nodes, in_dim=self.in_dim, out_dim=self.out_dim,
+                          kernel_size=self.kernel_size, blocks=self.blocks, layers=self.layers,
+                          skip_channels=self.skip_channels, end_channels=self.end_channels,
+                          gcn=self._use_gcn(), adaptive=self._use_gcn() and self.addaptadj,
+                          dropout=self.dropout, names=names)
+        cfg.grad_out = getattr(self, '_mo_grad_out', None)
+        cfg.grad_ready = getattr(self, '_mo_grad_ready', None)
+        cfg.dense_bf16 = (getattr(self, 'dense_dtype', 'f32') == 'bf16')
+        return cfg
+
     def body(self, x):
         """graph_wavenet.py:191-254 on a (B, in_dim, N, T) tensor -> (B, out_dim, N, T_final)."""
         if not x.is_cuda:
@@ -241,14 +252,7 @@ class gwnet(nn.Module):
         cache = tree_cache(self, '_mo_named')
         named = cache.named
         params = [named[k] for k in names]
-        cfg = GwnetConfig(num_nodes=self.num_nodes, in_dim=self.in_dim, out_dim=self.out_dim,
-                          kernel_size=self.kernel_size, blocks=self.blocks, layers=self.layers,
-                          skip_channels=self.skip_channels, end_channels=self.end_channels,
-                          gcn=self._use_gcn(), adaptive=self._use_gcn() and self.addaptadj,
-                          dropout=self.dropout, names=names)
-        cfg.grad_out = getattr(self, '_mo_grad_out', None)
-        cfg.grad_ready = getattr(self, '_mo_grad_ready', None)
-        cfg.dense_bf16 = (getattr(self, 'dense_dtype', 'f32') == 'bf16')
+        cfg = self._config(names)
         bn_bufs = [cache.bn[f'bn.{i}'][:2] for i in range(len(self.bn))]
         if self.training:
             for m in self.bn:
@@ -275,3 +279,41 @@ class gwnet(nn.Module):
             y = self.body(x)
             return y.view(self.num_nodes, self.horizon, self.out_dim)
         return self.body(input)
+
+    # ------------------------------------------------------------------ several reference-style calls in one launch
+    def _small_dense(self, device):
+        """The static supports for the small-graph kernel: None for an identity matrix (the reference's default support,
+        graph_wavenet.py:13-32 -- folded into the mlp weights), else the dense (N,N) matrix on the device."""
+        c = self.__dict__.get('_mo_small_dense')
+        if c is None or c[0] != device:
+            sup = self.supports if self._use_gcn() else []
+            eye = np.eye(self.num_nodes, dtype=np.float32)
+            mats = [None if np.array_equal(np.asarray(a, dtype=np.float32), eye)
+                    else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device) for a in sup]
+            c = self.__dict__['_mo_small_dense'] = (device, mats)
+        return c[1]
+
+    def forward_calls(self, inputs):
+        """``torch.stack([self(inputs[b]) for b in range(B)])`` for reference-style 3-D inputs (B, N, H, in_dim) ->
+        (B, N, H, out_dim): the per-batch-element calls of Modified_UNET.forward (unet.py:221-226), every call a batch of
+        one window with its own BatchNorm statistics and its own sequential running-statistic update.  On a small graph
+        with kernel_size 1 (the reference default) all calls run as ONE launch of the small-graph kernel
+        (csrc/gwnet_small.hip: a call = one workgroup); anything else loops over the general engine."""
+        B = inputs.shape[0]
+        cfg = self._config(self._engine_names()) if inputs.is_cuda else None
+        statics_n = len(self.supports) if (self._use_gcn() and self.supports) else 0
+        if (cfg is None or inputs.dim() != 4 or not small_supported(cfg, statics_n, self.horizon)
+                or getattr(self, 'small_graph_kernel', True) is False):
+            if B > 1:
+                self._mo_grad_out = None       # several backward passes through the engine must accumulate via autograd
+            return torch.stack([self(inputs[b]) for b in range(B)])
+        names = cfg.names
+        cache = tree_cache(self, '_mo_named')
+        params = [cache.named[k] for k in names]
+        bn_bufs = [cache.bn[f'bn.{i}'][:2] for i in range(len(self.bn))]
+        if self.training:
+            for m in self.bn:
+                m.num_batches_tracked += B                      # one BatchNorm2d call per layer and forward call
+        x = inputs.float().contiguous().view(B, self.in_dim, self.num_nodes, self.horizon)    # :189, per call
+        y = GwnetSmallFunction.apply(cfg, self._small_dense(inputs.device), bn_bufs, self.training, x, *params)
+        return y.view(B, self.num_nodes, self.horizon, self.out_dim)                           # :255, per call
