@@ -307,8 +307,7 @@ int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int Co, const f
 /* OutConv + loss + OutConv backward in one pass -- the tail of training_step (lit.py:32-38 on unet.py:86-92: yhat =
  * OutConv(act(in)); loss = MSE(yhat, y); MAE / MAPE / RMSE).  yhat is consumed by the loss only, so it is formed in registers
  * (written to `yhat` only when that is not NULL); the pass also leaves da = d loss / d act(in) (Ci planes per image,
- * MO_BF_OUT: bf16) and the slab rows of dW / db in `ws`, all for an upstream gradient d loss = 1 (consumers scale:
- * mo_unet_act_bwd's out_scale, mo_outc_loss_bwd's scale).  target: Co planes of HW floats per image at
+ * MO_BF_OUT: bf16) for an upstream gradient d loss = 1 (the consumer scales: mo_unet_act_bwd's out_scale).  target: Co planes of HW floats per image at
  * target + (target_off ? target_off[img] : img * Co * HW)  (lit.py:31 hands a permuted view of the batch).
  * out4 = {mse, mae, mape, rmse} (MAPE eps 1.17e-6, as torchmetrics).  Ci <= 4, Co <= 16. */
 long mo_outc_loss_ws_floats(long n_img, int HW, int Ci, int Co);
@@ -316,9 +315,13 @@ int mo_outc_loss_fwd(const float* in, long istride, int Ci, const float* sc, con
                      const float* W, const float* b, int Co, const float* target, const long long* target_off,
                      long n_img, int HW, float* yhat, float* da, long dastride, float* ws, float* out4,
                      int dtypes /* MO_BF_IN0 | MO_BF_OUT (da) */, void* stream);
-/* dW (Co,Ci), db (Co) = (sum of ws's slab rows) * *scale  (scale: device scalar, the upstream gradient of the loss; NULL = 1) */
-int mo_outc_loss_bwd(const float* ws, long n_img, int HW, int Ci, int Co, const float* scale, float* dW, float* db,
-                     void* stream);
+/* the weight / bias gradient of that OutConv, beside the data-flow chain: a second pass over the same input view and target
+ * re-forms d and sums dW (Co,Ci), db (Co), multiplied by *scale (device scalar: the upstream gradient of the loss; NULL = 1).
+ * ws: a workspace of mo_outc_loss_ws_floats floats (may be the forward's). */
+int mo_outc_loss_bwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu, int gsize,
+                     const float* W, const float* b, int Co, const float* target, const long long* target_off,
+                     long n_img, int HW, float* ws, const float* scale, float* dW, float* db,
+                     int dtypes /* MO_BF_IN0 */, void* stream);
 /* Up.up (unet.py:71): ConvTranspose2d(Ci, Co, k=2, s=2) with bias; W (Ci, Co, 2, 2); H,Wd = input size */
 int mo_convt2x2_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                     int gsize, const float* W, const float* b, int Co, long n_img, int H, int Wd, float* out,

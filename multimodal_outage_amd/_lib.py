@@ -103,7 +103,7 @@ SIGNATURES = {
     'mo_outc_loss_ws_floats': (i64, [i64, i32, i32, i32]),
     'mo_outc_loss_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp, vp, i64, vp, vp, i32,
                                vp]),
-    'mo_outc_loss_bwd': (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp]),
+    'mo_outc_loss_bwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp]),
     'mo_nchw_channel_sum': (i32, [vp, i64, i32, i64, i32, vp, vp, vp]),
     'mo_maxpool2_bwd': (i32, [vp, i64, i32, i64, i32, i32, vp, i64, vp, i64, vp]),
     'mo_raster_prepare': (i32, [vp, i64, i32, i32, f32, f32, f32, vp, i32, i32, vp]),

@@ -542,9 +542,17 @@ extern "C" int mo_nchw_conv1x1_bwd_weight(const float* dout, long dostride, int 
 // OutConv + MSE / metrics + OutConv backward in one pass (training_step: lit.py:32-38 on unet.py:86-92)
 // ------------------------------------------------------------------------------------------------
 static void outc_loss_grid(long n_img, int HW, int& gx, long& ipw, long& gy) {
-  gx = HW / 4096; if (gx < 1) gx = 1; if (gx > 16) gx = 16;
+  gx = HW / 8192; if (gx < 1) gx = 1; if (gx > 16) gx = 16;      // >= 8 pieces per thread: the block reduction (71 sums) is amortised
   ipw = (n_img * gx + 8191) / 8192; if (ipw < 1) ipw = 1;
   gy = (n_img + ipw - 1) / ipw;
+}
+template <int MODE>
+static void outc_loss_launch(const UtLossArgs& a, dim3 grid, hipStream_t st) {
+  if (a.Co <= 1) hipLaunchKernelGGL((ut_outc_loss_kernel<1, MODE>), grid, dim3(256), 0, st, a);
+  else if (a.Co <= 4) hipLaunchKernelGGL((ut_outc_loss_kernel<4, MODE>), grid, dim3(256), 0, st, a);
+  else if (a.Co <= 8) hipLaunchKernelGGL((ut_outc_loss_kernel<8, MODE>), grid, dim3(256), 0, st, a);
+  else if (a.Co <= 13) hipLaunchKernelGGL((ut_outc_loss_kernel<13, MODE>), grid, dim3(256), 0, st, a);      // BASELINE config 3
+  else hipLaunchKernelGGL((ut_outc_loss_kernel<16, MODE>), grid, dim3(256), 0, st, a);
 }
 extern "C" long mo_outc_loss_ws_floats(long n_img, int HW, int Ci, int Co) {
   int gx; long ipw, gy; outc_loss_grid(n_img, HW, gx, ipw, gy);
@@ -568,20 +576,30 @@ extern "C" int mo_outc_loss_fwd(const float* in, long istride, int Ci, const flo
   a.inv_n2 = (float)(2.0 / n_elem);
   hipStream_t st = ST(stream);
   dim3 grid(gx, (unsigned)gy);
-  if (Co <= 1) hipLaunchKernelGGL((ut_outc_loss_kernel<1>), grid, dim3(256), 0, st, a);
-  else if (Co <= 4) hipLaunchKernelGGL((ut_outc_loss_kernel<4>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((ut_outc_loss_kernel<16>), grid, dim3(256), 0, st, a);
+  outc_loss_launch<0>(a, grid, st);
   const int nw = Co * Ci, ncol = nw + Co + 3;
   hipLaunchKernelGGL(ut_outc_loss_final_kernel, dim3(3), dim3(256), 0, st, ws, (int)(gx * gy), ncol, nw, Co, 0, n_elem,
                      (const float*)nullptr, (float*)nullptr, (float*)nullptr, out4);
   return mo_launch_status();
 }
-extern "C" int mo_outc_loss_bwd(const float* ws, long n_img, int HW, int Ci, int Co, const float* scale, float* dW,
-                                float* db, void* stream) {
-  MO_CHECK_ARG(ws && dW && Ci > 0 && Ci <= 4 && Co > 0 && Co <= 16 && n_img > 0 && HW > 0);
+extern "C" int mo_outc_loss_bwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
+                                int gsize, const float* W, const float* b, int Co, const float* target,
+                                const long long* target_off, long n_img, int HW, float* ws, const float* scale,
+                                float* dW, float* db, int dtypes, void* stream) {
+  MO_CHECK_ARG(in && W && target && ws && dW && Ci > 0 && Ci <= 4 && Co > 0 && Co <= 16 && n_img > 0 && HW > 0);
+  MO_CHECK_ARG((HW % 4) == 0 && (istride & 3) == 0 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)target) & 15) == 0);
   int gx; long ipw, gy; outc_loss_grid(n_img, HW, gx, ipw, gy);
+  MO_CHECK_ARG(gy <= 65535);
+  UtLossArgs a; a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize;
+  a.bfi = (dtypes & MO_BF_IN0) != 0; a.W = W; a.b = b; a.Co = Co; a.tgt = target;
+  a.tgt_off = reinterpret_cast<const long*>(target_off); a.tgt_stride = (long)Co * HW;
+  a.yhat = nullptr; a.ys = 0; a.da = nullptr; a.das = 0; a.bfda = 0; a.slab = ws;
+  a.n_img = n_img; a.HW = HW; a.img_per_wg = (int)ipw;
+  a.inv_n2 = (float)(2.0 / ((double)n_img * Co * HW));
+  hipStream_t st = ST(stream);
+  outc_loss_launch<1>(a, dim3(gx, (unsigned)gy), st);
   const int nw = Co * Ci, ncol = nw + Co + 3;
-  hipLaunchKernelGGL(ut_outc_loss_final_kernel, dim3(nw + Co), dim3(256), 0, ST(stream), ws, (int)(gx * gy), ncol, nw, Co, 1,
+  hipLaunchKernelGGL(ut_outc_loss_final_kernel, dim3(nw + Co), dim3(256), 0, st, ws, (int)(gx * gy), ncol, nw, Co, 1,
                      1.0, scale, dW, db, (float*)nullptr);
   return mo_launch_status();
 }

@@ -340,22 +340,29 @@ struct UtLossArgs {
   float* slab;                                           // [workgroups][Co*Ci + Co + 3]
   long n_img; int HW, img_per_wg; float inv_n2;          // 2 / (number of elements of yhat)
 };
-template <int CO>
-__global__ __launch_bounds__(256) void ut_outc_loss_kernel(UtLossArgs a) {
-  constexpr int CI = 4, NS = CO * CI + CO + 3;
-  __shared__ float wsm[CO][CI];
-  __shared__ float bsm[CO];
+// MODE 0 (forward, on the data-flow chain): the three loss sums + da.  MODE 1 (backward, beside the chain): the weight /
+// bias gradient sums, re-reading the input view and the target and re-forming d (a second 0.5 GB pass on the
+// weight-gradient lane: one kernel holding the Co*Ci + Co weight-gradient accumulators AND every load of a piece in flight
+// needed > 256 VGPRs).  Branch-free bodies: every load of a piece (CI input quads, CO target quads) is issued before the
+// first use -- with the loads inside `if (co < Co)` blocks the first version kept 13 dependent load -> use chains per
+// piece and ran at 1.05 TB/s.  Channels past Co re-read the last real plane (a cache hit) and are masked out; the
+// weights are wave-uniform scalar loads.
+template <int CO, int MODE>
+__global__ __launch_bounds__(256, 2) void ut_outc_loss_kernel(UtLossArgs a) {
+  constexpr int CI = 4, NS = MODE ? CO * CI + CO : 3;
   __shared__ float red[4][NS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < CO * CI; i += 256) {
-    const int co = i / CI, ci = i - co * CI;
-    wsm[co][ci] = (co < a.Co && ci < a.Ci) ? a.W[(long)co * a.Ci + ci] : 0.f;
-  }
-  if (tid < CO) bsm[tid] = (a.b && tid < a.Co) ? a.b[tid] : 0.f;
-  __syncthreads();
-  float accw[CO][CI], accb[CO], s_sq = 0.f, s_abs = 0.f, s_ape = 0.f;
+  float wsm[CO][CI], bsm[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
+    const int cc = min(co, a.Co - 1);
+    bsm[co] = a.b ? a.b[cc] : 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) wsm[co][ci] = a.W[(long)cc * a.Ci + min(ci, a.Ci - 1)];
+  }
+  float accw[MODE ? CO : 1][CI], accb[MODE ? CO : 1], s_sq = 0.f, s_abs = 0.f, s_ape = 0.f;
+#pragma unroll
+  for (int co = 0; co < (MODE ? CO : 1); ++co) {
     accb[co] = 0.f;
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci) accw[co][ci] = 0.f;
@@ -364,20 +371,26 @@ __global__ __launch_bounds__(256) void ut_outc_loss_kernel(UtLossArgs a) {
   for (long img = img0; img < img1; ++img) {
     const long grp = img / a.gsize;
     const float* tg = a.tgt + (a.tgt_off ? a.tgt_off[img] : img * a.tgt_stride);
+    float sc[CI], sh[CI];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+      const int cc = min(ci, a.Ci - 1);
+      sc[ci] = a.sc ? a.sc[grp * a.Ci + cc] : 1.f; sh[ci] = a.sc ? a.sh[grp * a.Ci + cc] : 0.f;
+    }
     for (int p = (blockIdx.x * 256 + tid) * 4; p < a.HW; p += gridDim.x * 1024) {
+      float4 xv[CI], tq[CO];
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) xv[ci] = ua_ld4(a.in, img * a.is + (long)min(ci, a.Ci - 1) * a.HW + p, a.bfi);
+#pragma unroll
+      for (int co = 0; co < CO; ++co) tq[co] = *reinterpret_cast<const float4*>(tg + (long)min(co, a.Co - 1) * a.HW + p);
       float x[CI][4];
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ci < a.Ci) {
-          v = ua_ld4(a.in, img * a.is + (long)ci * a.HW + p, a.bfi);
-          if (a.sc) {
-            const float s = a.sc[grp * a.Ci + ci], t = a.sh[grp * a.Ci + ci];
-            v.x = v.x * s + t; v.y = v.y * s + t; v.z = v.z * s + t; v.w = v.w * s + t;
-          }
-          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        }
-        x[ci][0] = v.x; x[ci][1] = v.y; x[ci][2] = v.z; x[ci][3] = v.w;
+        float4 v = xv[ci];
+        v.x = v.x * sc[ci] + sh[ci]; v.y = v.y * sc[ci] + sh[ci]; v.z = v.z * sc[ci] + sh[ci]; v.w = v.w * sc[ci] + sh[ci];
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const float keep = ci < a.Ci ? 1.f : 0.f;
+        x[ci][0] = v.x * keep; x[ci][1] = v.y * keep; x[ci][2] = v.z * keep; x[ci][3] = v.w * keep;
       }
       float dacc[CI][4];
 #pragma unroll
@@ -386,32 +399,35 @@ __global__ __launch_bounds__(256) void ut_outc_loss_kernel(UtLossArgs a) {
         for (int k = 0; k < 4; ++k) dacc[ci][k] = 0.f;
 #pragma unroll
       for (int co = 0; co < CO; ++co) {
-        if (co < a.Co) {
-          const float4 t4 = *reinterpret_cast<const float4*>(tg + (long)co * a.HW + p);
-          const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
-          float o[4], d[4];
+        const float valid = co < a.Co ? 1.f : 0.f;
+        const float tv[4] = {tq[co].x, tq[co].y, tq[co].z, tq[co].w};
+        float o[4], d[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float s = bsm[co];
+        for (int k = 0; k < 4; ++k) {
+          float s = bsm[co];
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) s += wsm[co][ci] * x[ci][k];
-            o[k] = s;
-            const float e = s - tv[k], ae = fabsf(e);
-            s_sq += e * e; s_abs += ae; s_ape += ae / fmaxf(fabsf(tv[k]), 1.17e-06f);
-            d[k] = e * a.inv_n2;
-          }
-          if (a.yhat) *reinterpret_cast<float4*>(a.yhat + img * a.ys + (long)co * a.HW + p) = make_float4(o[0], o[1], o[2], o[3]);
-          accb[co] += (d[0] + d[1]) + (d[2] + d[3]);
+          for (int ci = 0; ci < CI; ++ci) s += wsm[co][ci] * x[ci][k];
+          o[k] = s;
+          const float e = (s - tv[k]) * valid;
+          if (MODE == 0) { const float ae = fabsf(e); s_sq += e * e; s_abs += ae; s_ape += ae / fmaxf(fabsf(tv[k]), 1.17e-06f); }
+          d[k] = e * a.inv_n2;
+        }
+        if (MODE == 0) {
+          if (a.yhat && co < a.Co) *reinterpret_cast<float4*>(a.yhat + img * a.ys + (long)co * a.HW + p) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
           for (int ci = 0; ci < CI; ++ci) {
             const float w = wsm[co][ci];
-            accw[co][ci] += (d[0] * x[ci][0] + d[1] * x[ci][1]) + (d[2] * x[ci][2] + d[3] * x[ci][3]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) dacc[ci][k] += w * d[k];
           }
+        } else {
+          accb[co] += (d[0] + d[1]) + (d[2] + d[3]);
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci)
+            accw[co][ci] += (d[0] * x[ci][0] + d[1] * x[ci][1]) + (d[2] * x[ci][2] + d[3] * x[ci][3]);
         }
       }
-      if (a.da) {
+      if (MODE == 0 && a.da) {
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
           if (ci < a.Ci) ua_st4(a.da, img * a.das + (long)ci * a.HW + p, make_float4(dacc[ci][0], dacc[ci][1], dacc[ci][2], dacc[ci][3]), a.bfda);
@@ -422,21 +438,24 @@ __global__ __launch_bounds__(256) void ut_outc_loss_kernel(UtLossArgs a) {
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     float v;
-    if (i < CO * CI) v = accw[i / CI][i % CI];
-    else if (i < CO * CI + CO) v = accb[i - CO * CI];
-    else v = (i == NS - 3) ? s_sq : (i == NS - 2) ? s_abs : s_ape;
+    if (MODE) v = i < CO * CI ? accw[i / CI][i % CI] : accb[i - CO * CI];
+    else v = i == 0 ? s_sq : i == 1 ? s_abs : s_ape;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
-  const int nw = a.Co * a.Ci, nout = nw + a.Co + 3;
-  float* row = a.slab + ((long)blockIdx.y * gridDim.x + blockIdx.x) * nout;
-  for (int i = tid; i < nout; i += 256) {
-    int src;
-    if (i < nw) { const int co = i / a.Ci, ci = i - co * a.Ci; src = co * CI + ci; }
-    else src = CO * CI + (i - nw) + (i >= nw + a.Co ? CO - a.Co : 0);
-    row[i] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+  const int nw = a.Co * a.Ci, ncol = nw + a.Co + 3;
+  float* row = a.slab + ((long)blockIdx.y * gridDim.x + blockIdx.x) * ncol;
+  if (MODE) {
+    for (int i = tid; i < nw + a.Co; i += 256) {
+      int src;
+      if (i < nw) { const int co = i / a.Ci, ci = i - co * a.Ci; src = co * CI + ci; }
+      else src = CO * CI + (i - nw);
+      row[i] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+    }
+  } else if (tid < 3) {
+    row[nw + a.Co + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 // column sums of the slab in double, fixed order.  mode 0 (forward): the last three columns -> out4 = {mse, mae, mape,

@@ -513,10 +513,14 @@ class UnetDecodeFn(torch.autograd.Function):
         dev = da.device
         st = L.stream()
         if loss_scale is not None:
+            # the OutConv's weight / bias gradient: a second pass over the same view and target, beside the chain
             Cout, C4 = dWo.shape[0], dWo.shape[1]
-            ws = ctx.loss_ws
-            lane.run(lambda ls: L.call('mo_outc_loss_bwd', L.ptr(ws), n, v.H * v.W, C4, Cout, L.ptr(loss_scale), L.ptr(dWo),
-                                       L.ptr(dbo), ls), reads=[ws, loss_scale, dWo, dbo])
+            ws, tgt, toff = ctx.loss_ws, state['target'], state.get('target_off')
+            Wo, bo = p['expansion.outc.conv.weight'], p['expansion.outc.conv.bias']
+            lane.run(lambda ls: L.call('mo_outc_loss_bwd', L.ptr(v.t), v.istride, v.C, L.ptr(v.sc), L.ptr(v.sh), 1, gs,
+                                       L.ptr(Wo), L.ptr(bo), Cout, tgt.data_ptr(), L.ptr(toff), n, v.H * v.W, L.ptr(ws),
+                                       L.ptr(loss_scale), L.ptr(dWo), L.ptr(dbo), L.BF_IN0 * v.bf, ls),
+                     reads=[ws, loss_scale, dWo, dbo, v.t, v.sc, v.sh, tgt, toff])
         dfm = [None] * 4
         for k in (4, 3, 2, 1):
             up = ctx.ups[k - 1]

@@ -416,7 +416,9 @@ def test_outconv_loss_fused(L, n, gs, Ci, Co, HW, perm, bf):
     close(da.float() * upstream, a.grad.reshape(n, Ci, HW), tol=4e-3 if bf else 1e-4, what='da')
     scale = dev(torch.tensor([upstream]))
     dW = torch.empty(Co, Ci, device='cuda'); db = torch.empty(Co, device='cuda')
-    L.call('mo_outc_loss_bwd', L.ptr(ws), n, HW, Ci, Co, L.ptr(scale), L.ptr(dW), L.ptr(db), L.stream())
+    L.call('mo_outc_loss_bwd', L.ptr(xd), Ci * HW, Ci, L.ptr(scd), L.ptr(shd), 1, gs, L.ptr(dev(Wt.detach())),
+           L.ptr(dev(b.detach())), Co, L.ptr(td), L.ptr(off), n, HW, L.ptr(ws), L.ptr(scale), L.ptr(dW), L.ptr(db),
+           L.BF_IN0 * bf, L.stream())
     close(dW, Wt.grad.reshape(Co, Ci), what='dW')
     close(db, b.grad, what='db')
     # without the optional prediction the results are the same bits
