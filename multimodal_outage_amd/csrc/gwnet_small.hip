@@ -22,8 +22,9 @@ typedef float sg_f4 __attribute__((ext_vector_type(4)));
 #define SG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define SG_MAXL 16
 #define SG_MAXS 3
-#define SG_THREADS 1024
-#define SG_WAVES 16
+#define SG_THREADS 768     // 12 waves: >= the 9..10 row strips of a phase at N*T = 134, and 170 VGPRs per lane (1024 threads: 128, spills)
+#define SG_WAVES 12
+#define SG_NR (SG_THREADS / 32)   // rows per sweep of the elementwise phases
 #define SG_LDW 66          // LDS row stride of a [k][64] weight image: % 4 == 2 -> the four k-groups of a wave hit disjoint banks
 #define SG_LDM 34          // ... of a [k][32] image
 
@@ -93,6 +94,15 @@ struct SgGeo {
   __device__ __forceinline__ long nrow(int n, int t) const { return ((long)n * B + b) * T + t; }
 };
 
+// Strided operand rows through buffer descriptors: ONE 32-bit lane offset per job plus a wave-uniform SGPR offset per
+// (k chunk, k step) -- 48 pointer-based loads in flight cost 96 VGPRs of addresses and the kernel spilled.  Rows past the
+// tensor (nodes >= N) fall out of the descriptor's range and read 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float sg_bl(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
 __device__ __forceinline__ void sg_ld8(const float* p, float* a) {
   const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + 4);
   a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w; a[4] = v.x; a[5] = v.y; a[6] = v.z; a[7] = v.w;
@@ -100,27 +110,34 @@ __device__ __forceinline__ void sg_ld8(const float* p, float* a) {
 
 // ------------------------------------------------------------------------------------------------ forward
 // dynamic LDS: adj [ndense][N][LDA] | wt [32][SG_LDW] (filter|gate, k-major) | wm [32 ne][SG_LDM] (k-major) | biases etc.
+// A wave's job is a strip of 16 rows with ALL its output columns (the A operand is loaded once) and every global load of a
+// job is issued before the first MFMA: a phase costs one L2 round trip, not one per 32-wide k chunk.
+template <int ND>
 __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
-  const int N = a.N, T = a.T, P = a.P, J = T * 32, LDA = N + 3 - ((N + 1) & 3);
+  constexpr int NE = 1 + 2 * ND;
+  const int tid = threadIdx.x, lane = tid & 63, wave_ = tid >> 6, l16 = lane & 15, q = lane >> 4;
+  const int N = a.N, T = a.T, P = a.P, LDA = N + 3 - ((N + 1) & 3);
   // LDA % 4 == 2 (bank spread of the four k groups): N + 3 - ((N + 1) & 3) is the smallest value >= N that is 2 (mod 4)
-  const int ne = 1 + 2 * a.ndense;
   float* adj_s = lds;
-  float* wt = adj_s + a.ndense * N * LDA;
+  float* wt = adj_s + ND * N * LDA;
   float* wm = wt + 32 * SG_LDW;
-  float* bias = wm + 32 * ne * SG_LDM;          // bf[32] bg[32] bm[32]
+  float* bias = wm + 32 * NE * SG_LDM;          // bf[32] bg[32] bm[32]
   float* aff = bias + 96;                        // scale[32] shift[32] of the layer input
   float* part = aff + 64;                        // [SG_WAVES][64] BatchNorm partial sums
   SgGeo g; g.B = a.B; g.T = T; g.P = P; g.N = N; g.b = blockIdx.x;
   const long rows = a.rows;
   const int ldg = 32 * a.L;
-  for (int d = 0; d < a.ndense; ++d)
+  for (int d = 0; d < ND; ++d)
     for (int i = tid; i < N * N; i += SG_THREADS) adj_s[(d * N + i / N) * LDA + i % N] = a.adj[d][i];
   const int mtiles = (P + 15) >> 4;
+  const int ntn = (N + 15) >> 4, kch = (N + 31) >> 5;     // N <= 80: kch <= 3
 
   for (int li = 0; li < a.L; ++li) {
     const SgLayer& Ly = a.ly[li];
+    // (the job -> row arithmetic below depends on the wave index only; laundering it keeps the compiler from hoisting two
+    //  dozen 64-bit row addresses out of the layer loop and holding them in VGPRs across every phase -- it spilled)
+    int wave = wave_; asm volatile("" : "+v"(wave));
     // ---- weights of the layer into LDS (k-major images); identity supports folded into the g block of the mlp
     for (int i = tid; i < 32 * 32; i += SG_THREADS) {
       const int co = i >> 5, ci = i & 31;
@@ -143,54 +160,68 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
     float* gout = a.gcat + li * 32;
 
     // ---- A: gated TCN (kernel_size 1: two 1x1 convs)  g = tanh(Wf x + bf) * sigmoid(Wg x + bg)
-    for (int job = wave; job < mtiles * 2; job += SG_WAVES) {
-      const int mt = job >> 1, nh = job & 1;
+    for (int mt = wave; mt < mtiles; mt += SG_WAVES) {
       const int pl = min(mt * 16 + l16, P - 1);
-      const float* xr = xin + g.row(pl) * 32 + 8 * q;
       float av[8];
-      sg_ld8(xr, av);
+      sg_ld8(xin + g.row(pl) * 32 + 8 * q, av);
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] = av[j] * aff[8 * q + j] + aff[32 + 8 * q + j];
-      sg_f4 af = {0.f, 0.f, 0.f, 0.f}, ag = af;
+      sg_f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        af = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + nh * 16 + l16], af);
-        ag = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + 32 + nh * 16 + l16], ag);
-      }
-      const int c = nh * 16 + l16;
+        const float* wr = wt + (8 * q + j) * SG_LDW + l16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int po = mt * 16 + 4 * q + i;
-        if (po < P) gout[g.row(po) * ldg + c] = sg_tanh(af[i] + bias[c]) * sg_sigmoid(ag[i] + bias[32 + c]);
+        for (int u = 0; u < 4; ++u) acc[u] = SG_MFMA(av[j], wr[16 * u], acc[u]);
+      }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const int c = nh * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int po = mt * 16 + 4 * q + i;
+          if (po < P) gout[g.row(po) * ldg + c] = sg_tanh(acc[nh][i] + bias[c]) * sg_sigmoid(acc[2 + nh][i] + bias[32 + c]);
+        }
       }
     }
     __syncthreads();
 
-    // ---- B: diffusion hops of the dense supports: x1 = A^T g, x2 = A^T x1 on the node axis ([N][T*32] matrices)
-    for (int hop = 0; hop < 2 && a.ndense > 0; ++hop) {
-      const int ntn = (N + 15) >> 4, ntj = J >> 4, kch = (N + 31) >> 5;
-      for (int job = wave; job < a.ndense * ntn * ntj; job += SG_WAVES) {
-        const int d = job / (ntn * ntj), r2 = job - d * (ntn * ntj), mt = r2 / ntj, nt = r2 - mt * ntj;
+    // ---- B: diffusion hops of the dense supports: x1 = A^T g, x2 = A^T x1 on the node axis ([N][T*32] matrices);
+    //      a job = 16 nodes x the 32 channels of one time step
+    for (int hop = 0; hop < 2 && ND > 0; ++hop) {
+      for (int job = wave; job < ND * ntn * T; job += SG_WAVES) {
+        const int d = job / (ntn * T), r2 = job - d * (ntn * T), mt = r2 / T, tt = r2 - mt * T;
         const float* As = adj_s + d * N * LDA;
-        float* x1 = a.xs + (((long)li * a.ndense + d) * 2) * rows * 32;
+        float* x1 = a.xs + (((long)li * ND + d) * 2) * rows * 32;
         const float* src = hop == 0 ? gout : x1;
         const int lds_ = hop == 0 ? ldg : 32;
         float* dst = hop == 0 ? x1 : x1 + rows * 32;
         const int wcl = min(mt * 16 + l16, N - 1);
-        const int jc = nt * 16 + l16, tt = jc >> 5, cc = jc & 31;
-        sg_f4 acc = sg_tile(kch,
-            [&](int kc, float* av) {
+        const __amdgpu_buffer_rsrc_t rs = sg_rsrc(src, (rows * lds_ - (hop == 0 ? li * 32 : 0)) * 4);
+        const int voff = (int)((g.nrow(8 * q, tt) * lds_ + l16) * 4), sstep = a.B * T * lds_ * 4;
+        float bv[3][2][8];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) { const int v = kc * 32 + 8 * q + j; av[j] = v < N ? As[v * LDA + wcl] : 0.f; }
-            },
-            [&](int kc, float* bv) {
+        for (int kc = 0; kc < 3; ++kc)
+          if (kc < kch) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) { const int v = min(kc * 32 + 8 * q + j, N - 1); bv[j] = src[g.nrow(v, tt) * lds_ + cc]; }
-            });
+            for (int j = 0; j < 8; ++j) {
+              bv[kc][0][j] = sg_bl(rs, voff, (kc * 32 + j) * sstep); bv[kc][1][j] = sg_bl(rs, voff + 64, (kc * 32 + j) * sstep);
+            }
+          }
+        sg_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc)
+          if (kc < kch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int v = kc * 32 + 8 * q + j;
+              const float av = v < N ? As[v * LDA + wcl] : 0.f;
+              acc0 = SG_MFMA(av, bv[kc][0][j], acc0); acc1 = SG_MFMA(av, bv[kc][1][j], acc1);
+            }
+          }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int w = mt * 16 + 4 * q + i;
-          if (w < N) dst[g.nrow(w, tt) * 32 + cc] = acc[i];
+          if (w < N) { float* o = dst + g.nrow(w, tt) * 32 + l16; o[0] = acc0[i]; o[16] = acc1[i]; }
         }
       }
       __syncthreads();
@@ -200,30 +231,37 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     float* hout = a.hs + (long)li * rows * 32;
     const uint32_t lseed = a.seed + 7919u * (uint32_t)li;
-    for (int job = wave; job < mtiles * 2; job += SG_WAVES) {
-      const int mt = job >> 1, nh = job & 1;
+    for (int mt = wave; mt < mtiles; mt += SG_WAVES) {
       const int pl = min(mt * 16 + l16, P - 1);
       const long r = g.row(pl);
-      sg_f4 acc = sg_tile(ne,
-          [&](int e, float* av) {
-            const float* s = e == 0 ? gout + r * ldg : a.xs + (((long)li * a.ndense) * 2 + (e - 1)) * rows * 32 + r * 32;
-            sg_ld8(s + 8 * q, av);
-          },
-          [&](int e, float* bv) {
+      float av[NE][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bv[j] = wm[(e * 32 + 8 * q + j) * SG_LDM + nh * 16 + l16];
-          });
-      const int c = nh * 16 + l16;
+      for (int e = 0; e < NE; ++e) {
+        const float* s = e == 0 ? gout + r * ldg : a.xs + (((long)li * ND) * 2 + (e - 1)) * rows * 32 + r * 32;
+        sg_ld8(s + 8 * q, av[e]);
+      }
+      sg_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int po = mt * 16 + 4 * q + i;
-        if (po < P) {
-          const long ro = g.row(po);
-          float v = acc[i] + bias[64 + c];
-          if (a.thresh) v = mo_hash32(lseed, (uint32_t)(ro * 32 + c)) < a.thresh ? 0.f : v * a.dscale;
-          v += xin[ro * 32 + c] * aff[c] + aff[32 + c];
-          hout[ro * 32 + c] = v;
-          s1[nh] += v; s2[nh] += v * v;
+      for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* wr = wm + (e * 32 + 8 * q + j) * SG_LDM + l16;
+          acc[0] = SG_MFMA(av[e][j], wr[0], acc[0]); acc[1] = SG_MFMA(av[e][j], wr[16], acc[1]);
+        }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const int c = nh * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int po = mt * 16 + 4 * q + i;
+          if (po < P) {
+            const long ro = g.row(po);
+            float v = acc[nh][i] + bias[64 + c];
+            if (a.thresh) v = mo_hash32(lseed, (uint32_t)(ro * 32 + c)) < a.thresh ? 0.f : v * a.dscale;
+            v += xin[ro * 32 + c] * aff[c] + aff[32 + c];
+            hout[ro * 32 + c] = v;
+            s1[nh] += v; s2[nh] += v * v;
+          }
         }
       }
     }
@@ -274,33 +312,66 @@ __global__ void sg_running_kernel(SgArgs a, float momentum) {
 // ------------------------------------------------------------------------------------------------ backward
 // dynamic LDS: adj | wt (k-major filter|gate, for the recompute) | wtn [64][SG_LDM] natural (data gradient of the TCN)
 //            | wmn [32][32 ne + 2] natural (data gradient of the mlp) | bias | aff | small reduction scratch
+// Jobs as in the forward (a strip of 16 rows x all columns, loads up front).  The weight-gradient tiles (k = the P
+// positions of the call) are dealt to the waves BEHIND the data jobs of the same phase: wave w's first weight tile is
+// (w - data jobs) mod 16, so the waves without a data job start on them at once.
+template <int ND>
 __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
-  const int N = a.N, T = a.T, P = a.P, J = T * 32, LDA = N + 3 - ((N + 1) & 3);
-  const int ne = 1 + 2 * a.ndense, LDN = 32 * ne + 2;
+  constexpr int NE = 1 + 2 * ND, LDN = 32 * NE + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave_ = tid >> 6, l16 = lane & 15, q = lane >> 4;
+  const int N = a.N, T = a.T, P = a.P, LDA = N + 3 - ((N + 1) & 3);
   float* adj_s = lds;
-  float* wt = adj_s + a.ndense * N * LDA;
+  float* wt = adj_s + ND * N * LDA;
   float* wtn = wt + 32 * SG_LDW;
   float* wmn = wtn + 64 * SG_LDM;
   float* bias = wmn + 32 * LDN;                 // bf | bg
   float* aff = bias + 64;                        // scale, shift of the layer input
   float* bnk = aff + 64;                         // gamma*rstd [32], k1 [32], k2 [32], mean [32], rstd [32]
-  double* red = reinterpret_cast<double*>(bnk + 160);    // [32][33] x 3 doubles ... sized below
+  double* red = reinterpret_cast<double*>(bnk + 160);    // [2][32][33] doubles
   SgGeo g; g.B = a.B; g.T = T; g.P = P; g.N = N; g.b = blockIdx.x;
   const long rows = a.rows;
   const int ldg = 32 * a.L;
   const long slabL = SG_S_WM + 32L * 32 * (1 + 2 * a.nsup);
-  for (int d = 0; d < a.ndense; ++d)
+  for (int d = 0; d < ND; ++d)
     for (int i = tid; i < N * N; i += SG_THREADS) adj_s[(d * N + i / N) * LDA + i % N] = a.adj[d][i];
-  const int mtiles = (P + 15) >> 4;
-  const int ntn = (N + 15) >> 4;
+  const int mtiles = (P + 15) >> 4, pch = (P + 31) >> 5;
+  const int ntn = (N + 15) >> 4, kch = (N + 31) >> 5;
   // persistent accumulators of the adaptive support's gradient: tile (mt, nt) of dA[v][w] owned by a fixed wave
-  sg_f4 accA[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  sg_f4 accA[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // 25 tiles at N = 67..80 / 12 waves
   const int nAt = (a.adaptive_dense >= 0 && a.dA) ? ntn * ntn : 0;
+
+  // one weight-gradient tile: D[16 x 16] = sum over the call's positions of A[p][m0 + .] * B[p][n0 + .].  The k order is
+  // free: k = (time step, node), so a lane's eight k are eight consecutive NODES at one time step -- a uniform row stride
+  // (B*T rows) that goes into the SGPR offset of a buffer load; nodes >= N read 0 from both operands.  fa(value, row)
+  // post-processes the A values (dropout mask), fb the B values (BatchNorm affine of the layer input).
+  auto wtile = [&](const float* pa, int lda, int ca, const float* pb, int ldb, int cb, auto fa, auto fb) {
+    sg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t ra = sg_rsrc(pa, rows * lda * 4), rb = sg_rsrc(pb, rows * ldb * 4);
+    const int sa = a.B * T * lda * 4, sb_ = a.B * T * ldb * 4;
+    for (int t = 0; t < T; ++t) {
+      const long r0 = g.nrow(8 * q, t);
+      const int va = (int)((r0 * lda + ca) * 4), vb = (int)((r0 * ldb + cb) * 4);
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc)
+        if (kc < kch) {
+          float av[8], bv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { av[j] = sg_bl(ra, va, (kc * 32 + j) * sa); bv[j] = sg_bl(rb, vb, (kc * 32 + j) * sb_); }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const long r = r0 + (long)(kc * 32 + j) * a.B * T;
+            acc = SG_MFMA(fa(av[j], r), fb(bv[j]), acc);
+          }
+        }
+    }
+    return acc;
+  };
 
   for (int li = a.L - 1; li >= 0; --li) {
     const SgLayer& Ly = a.ly[li];
+    int wave = wave_; asm volatile("" : "+v"(wave));      // (see sg_fwd_kernel)
+    const int wrot = (wave + SG_WAVES - (mtiles % SG_WAVES)) % SG_WAVES;     // first weight tile of this wave
     float* slab = a.slab + ((long)blockIdx.x * a.L + li) * slabL;
     const bool has_dh = li < a.L - 1;            // the last layer's gcn / bn output is dead (graph_wavenet.py:252)
     // ---- weights
@@ -331,13 +402,18 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
     const float* hl = a.hs + (long)li * rows * 32;
     const uint32_t lseed = a.seed + 7919u * (uint32_t)li;
     const int tr = tid >> 5, tc = tid & 31;       // elementwise phases: 32 rows x 32 channels per sweep
+    auto dhm = [&](long r, int c) {               // dropout-masked dh (the gradient of the mlp output)
+      float v = a.dh[r * 32 + c];
+      if (a.thresh) v = mo_hash32(lseed, (uint32_t)(r * 32 + c)) < a.thresh ? 0.f : v * a.dscale;
+      return v;
+    };
 
     if (has_dh) {
       // ---- R1: BatchNorm backward sums  s1 = sum dxo, s2 = sum dxo * xhat   (per channel over the call's P positions)
       {
         double s1 = 0.0, s2 = 0.0;
         const float mu = bnk[96 + tc], rs = bnk[128 + tc];
-        for (int pl = tr; pl < P; pl += 32) {
+        for (int pl = tr; pl < P; pl += SG_NR) {
           const long r = g.row(pl);
           const float d = a.dxo[r * 32 + tc];
           s1 += (double)d; s2 += (double)d * (double)((hl[r * 32 + tc] - mu) * rs);
@@ -347,7 +423,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
       __syncthreads();
       if (tid < 32) {
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < 32; ++k) { s1 += red[k * 33 + tid]; s2 += red[32 * 33 + k * 33 + tid]; }
+        for (int k = 0; k < SG_NR; ++k) { s1 += red[k * 33 + tid]; s2 += red[32 * 33 + k * 33 + tid]; }
         slab[SG_S_GA + tid] = (float)s2; slab[SG_S_BE + tid] = (float)s1;
         bnk[tid] = Ly.gamma[tid] * bnk[128 + tid];
         bnk[32 + tid] = (float)(s1 / P); bnk[64 + tid] = (float)(s2 / P);
@@ -357,7 +433,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
       {
         double s3 = 0.0;
         const float mu = bnk[96 + tc], rs = bnk[128 + tc], gr = bnk[tc], k1 = bnk[32 + tc], k2 = bnk[64 + tc];
-        for (int pl = tr; pl < P; pl += 32) {
+        for (int pl = tr; pl < P; pl += SG_NR) {
           const long r = g.row(pl);
           const float v = gr * (a.dxo[r * 32 + tc] - k1 - (hl[r * 32 + tc] - mu) * rs * k2);
           a.dh[r * 32 + tc] = v;
@@ -370,149 +446,159 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
       __syncthreads();
       if (tid < 32) {
         double s3 = 0.0;
-        for (int k = 0; k < 32; ++k) s3 += red[k * 33 + tid];
+        for (int k = 0; k < SG_NR; ++k) s3 += red[k * 33 + tid];
         slab[SG_S_BM + tid] = (float)s3;
       }
-      // ---- M: mlp backward.  data: dsrc_e = dhm @ Wm_eff[:, e]  (e = 0: dg = ... + skip-path gradient);
-      //      weights: dWm[co][e*32 + ci] = sum_p dhm[p][co] src_e[p][ci]
-      const int njd = mtiles * 2 * ne, njw = 2 * 2 * ne;
-      for (int job = wave; job < njd + njw; job += SG_WAVES) {
-        if (job < njd) {
-          const int mt = job / (2 * ne), nt = job - mt * (2 * ne);       // nt: 16-column tile of the 32 ne outputs
-          const int pl = min(mt * 16 + l16, P - 1);
-          const long r = g.row(pl);
-          float av[8];
-          sg_ld8(a.dh + r * 32 + 8 * q, av);
-          if (a.thresh) {
+      // ---- M: mlp backward.  data: dsrc_e = dhm @ Wm_eff[:, e]  (e = 0: dg = ... + skip-path gradient)
+      for (int mt = wave; mt < mtiles; mt += SG_WAVES) {
+        const int pl = min(mt * 16 + l16, P - 1);
+        const long r = g.row(pl);
+        float av[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) av[j] = mo_hash32(lseed, (uint32_t)(r * 32 + 8 * q + j)) < a.thresh ? 0.f : av[j] * a.dscale;
-          }
-          sg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) av[j] = dhm(r, 8 * q + j);
+        sg_f4 acc[2 * NE];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc = SG_MFMA(av[j], wmn[(8 * q + j) * LDN + nt * 16 + l16], acc);
-          const int e = nt >> 1, c = (nt & 1) * 16 + l16;
+        for (int u = 0; u < 2 * NE; ++u) acc[u] = (sg_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* wr = wmn + (8 * q + j) * LDN + l16;
+#pragma unroll
+          for (int u = 0; u < 2 * NE; ++u) acc[u] = SG_MFMA(av[j], wr[16 * u], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * NE; ++u) {
+          const int e = u >> 1, c = (u & 1) * 16 + l16;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int po = mt * 16 + 4 * q + i;
             if (po < P) {
               const long ro = g.row(po);
-              if (e == 0) a.dg[ro * 32 + c] = acc[i] + a.dgskip[ro * ldg + li * 32 + c];
-              else a.dxs[(long)(e - 1) * rows * 32 + ro * 32 + c] = acc[i];
-            }
-          }
-        } else {
-          const int jw = job - njd, ct = jw / (2 * ne), nt = jw - ct * (2 * ne);
-          const int e = nt >> 1, ci = (nt & 1) * 16 + l16, co = ct * 16 + l16;
-          const float* s = e == 0 ? gl : a.xs + (((long)li * a.ndense) * 2 + (e - 1)) * rows * 32;
-          const int lds_ = e == 0 ? ldg : 32;
-          sg_f4 acc = sg_tile((P + 31) >> 5,
-              [&](int kc, float* av) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  const int pl = kc * 32 + 8 * q + j;
-                  float v = 0.f;
-                  if (pl < P) {
-                    const long r = g.row(pl);
-                    v = a.dh[r * 32 + co];
-                    if (a.thresh) v = mo_hash32(lseed, (uint32_t)(r * 32 + co)) < a.thresh ? 0.f : v * a.dscale;
-                  }
-                  av[j] = v;
-                }
-              },
-              [&](int kc, float* bv) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const int pl = min(kc * 32 + 8 * q + j, P - 1); bv[j] = s[g.row(pl) * lds_ + ci]; }
-              });
-          // rows co = ct*16 + 4q + i, column e*32 + (nt&1)*16 + l16; the g block also is the gradient of every identity block
-          const int W = 32 * (1 + 2 * a.nsup);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float* drow = slab + SG_S_WM + (long)(ct * 16 + 4 * q + i) * W;
-            if (e == 0) {
-              drow[ci] = acc[i];
-              for (int k = 0; k < a.nsup; ++k)
-                if (a.dense_of[k] < 0) { drow[32 * (1 + 2 * k) + ci] = acc[i]; drow[32 * (2 + 2 * k) + ci] = acc[i]; }
-            } else {
-              int k = 0;
-              for (; k < a.nsup; ++k) if (a.dense_of[k] == ((e - 1) >> 1)) break;
-              drow[32 * (1 + 2 * k + ((e - 1) & 1)) + ci] = acc[i];
+              if (e == 0) a.dg[ro * 32 + c] = acc[u][i] + a.dgskip[ro * ldg + li * 32 + c];
+              else a.dxs[(long)(e - 1) * rows * 32 + ro * 32 + c] = acc[u][i];
             }
           }
         }
       }
+      //      weights: dWm[co][e*32 + ci] = sum_p dhm[p][co] src_e[p][ci]
+      for (int jw = wrot; jw < 2 * 2 * NE; jw += SG_WAVES) {
+        const int ct = jw / (2 * NE), nt = jw - ct * (2 * NE);
+        const int e = nt >> 1, ci = (nt & 1) * 16 + l16, co = ct * 16 + l16;
+        const float* s = e == 0 ? gl : a.xs + (((long)li * ND) * 2 + (e - 1)) * rows * 32;
+        const int lds_ = e == 0 ? ldg : 32;
+        const sg_f4 acc = wtile(a.dh, 32, co, s, lds_, ci,
+            [&](float v, long r) { return a.thresh ? (mo_hash32(lseed, (uint32_t)(r * 32 + co)) < a.thresh ? 0.f : v * a.dscale) : v; },
+            [&](float v) { return v; });
+        // rows co = ct*16 + 4q + i, column e*32 + (nt&1)*16 + l16; the g block also is the gradient of every identity block
+        const int W = 32 * (1 + 2 * a.nsup);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float* drow = slab + SG_S_WM + (long)(ct * 16 + 4 * q + i) * W;
+          if (e == 0) {
+            drow[ci] = acc[i];
+            for (int k = 0; k < a.nsup; ++k)
+              if (a.dense_of[k] < 0) { drow[32 * (1 + 2 * k) + ci] = acc[i]; drow[32 * (2 + 2 * k) + ci] = acc[i]; }
+          } else {
+            int k = 0;
+            for (; k < a.nsup - 1; ++k) if (a.dense_of[k] == ((e - 1) >> 1)) break;
+            drow[32 * (1 + 2 * k + ((e - 1) & 1)) + ci] = acc[i];
+          }
+        }
+      }
       __syncthreads();
-      // ---- N1: dx1_d += A_d dx2_d
-      if (a.ndense > 0) {
-        const int ntj = J >> 4, kch = (N + 31) >> 5;
-        for (int job = wave; job < a.ndense * ntn * ntj; job += SG_WAVES) {
-          const int d = job / (ntn * ntj), r2 = job - d * (ntn * ntj), mt = r2 / ntj, nt = r2 - mt * ntj;
+      if (ND > 0) {
+        // ---- N1: dx1_d += A_d dx2_d   (a job = 16 nodes x the 32 channels of one time step)
+        for (int job = wave; job < ND * ntn * T; job += SG_WAVES) {
+          const int d = job / (ntn * T), r2 = job - d * (ntn * T), mt = r2 / T, tt = r2 - mt * T;
           const float* As = adj_s + d * N * LDA;
           float* dx1 = a.dxs + (long)(2 * d) * rows * 32;
           const float* dx2 = dx1 + rows * 32;
           const int vcl = min(mt * 16 + l16, N - 1);
-          const int jc = nt * 16 + l16, tt = jc >> 5, cc = jc & 31;
-          sg_f4 acc = sg_tile(kch,
-              [&](int kc, float* av) {
+          const __amdgpu_buffer_rsrc_t rs = sg_rsrc(dx2, rows * 32 * 4);
+          const int voff = (int)((g.nrow(8 * q, tt) * 32 + l16) * 4), sstep = a.B * T * 32 * 4;
+          float bv[3][2][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const int w = kc * 32 + 8 * q + j; av[j] = w < N ? As[vcl * LDA + w] : 0.f; }
-              },
-              [&](int kc, float* bv) {
+          for (int kc = 0; kc < 3; ++kc)
+            if (kc < kch) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const int w = min(kc * 32 + 8 * q + j, N - 1); bv[j] = dx2[g.nrow(w, tt) * 32 + cc]; }
-              });
+              for (int j = 0; j < 8; ++j) {
+                bv[kc][0][j] = sg_bl(rs, voff, (kc * 32 + j) * sstep); bv[kc][1][j] = sg_bl(rs, voff + 64, (kc * 32 + j) * sstep);
+              }
+            }
+          sg_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int v = mt * 16 + 4 * q + i;
-            if (v < N) dx1[g.nrow(v, tt) * 32 + cc] += acc[i];
-          }
-        }
-        __syncthreads();
-        // ---- N2: dg += sum_d A_d dx1_d ;  dA += x1^T-products of the adaptive support
-        const int njg = ntn * ntj;
-        for (int job = wave; job < njg; job += SG_WAVES) {
-          const int mt = job / ntj, nt = job - mt * ntj;
-          const int vcl = min(mt * 16 + l16, N - 1);
-          const int jc = nt * 16 + l16, tt = jc >> 5, cc = jc & 31;
-          sg_f4 acc = {0.f, 0.f, 0.f, 0.f};
-          for (int d = 0; d < a.ndense; ++d) {
-            const float* As = adj_s + d * N * LDA;
-            const float* dx1 = a.dxs + (long)(2 * d) * rows * 32;
-            for (int kc = 0; kc < kch; ++kc) {
+          for (int kc = 0; kc < 3; ++kc)
+            if (kc < kch) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 const int w = kc * 32 + 8 * q + j;
                 const float av = w < N ? As[vcl * LDA + w] : 0.f;
-                const float bv = dx1[g.nrow(min(w, N - 1), tt) * 32 + cc];
-                acc = SG_MFMA(av, bv, acc);
+                acc0 = SG_MFMA(av, bv[kc][0][j], acc0); acc1 = SG_MFMA(av, bv[kc][1][j], acc1);
               }
             }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int v = mt * 16 + 4 * q + i;
+            if (v < N) { float* o = dx1 + g.nrow(v, tt) * 32 + l16; o[0] += acc0[i]; o[16] += acc1[i]; }
+          }
+        }
+        __syncthreads();
+        // ---- N2: dg += sum_d A_d dx1_d ;  dA += x1^T-products of the adaptive support
+        for (int job = wave; job < ntn * T; job += SG_WAVES) {
+          const int mt = job / T, tt = job - mt * T;
+          const int vcl = min(mt * 16 + l16, N - 1);
+          sg_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            const float* As = adj_s + d * N * LDA;
+            const float* dx1 = a.dxs + (long)(2 * d) * rows * 32;
+            const __amdgpu_buffer_rsrc_t rs = sg_rsrc(dx1, rows * 32 * 4);
+            const int voff = (int)((g.nrow(8 * q, tt) * 32 + l16) * 4), sstep = a.B * T * 32 * 4;
+            float bv[3][2][8];
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc)
+              if (kc < kch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  bv[kc][0][j] = sg_bl(rs, voff, (kc * 32 + j) * sstep); bv[kc][1][j] = sg_bl(rs, voff + 64, (kc * 32 + j) * sstep);
+                }
+              }
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc)
+              if (kc < kch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int w = kc * 32 + 8 * q + j;
+                  const float av = w < N ? As[vcl * LDA + w] : 0.f;
+                  acc0 = SG_MFMA(av, bv[kc][0][j], acc0); acc1 = SG_MFMA(av, bv[kc][1][j], acc1);
+                }
+              }
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int v = mt * 16 + 4 * q + i;
-            if (v < N) a.dg[g.nrow(v, tt) * 32 + cc] += acc[i];
+            if (v < N) { float* o = a.dg + g.nrow(v, tt) * 32 + l16; o[0] += acc0[i]; o[16] += acc1[i]; }
           }
         }
         if (nAt) {
           const int d = a.adaptive_dense;
-          const float* x1 = a.xs + (((long)li * a.ndense + d) * 2) * rows * 32;
+          const float* x1 = a.xs + (((long)li * ND + d) * 2) * rows * 32;
           const float* dx1 = a.dxs + (long)(2 * d) * rows * 32;
           const float* dx2 = dx1 + rows * 32;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int job = wave + s * SG_WAVES;
+          for (int s = 0; s < 3; ++s) {
+            const int job = ((wave + 6) % SG_WAVES) + s * SG_WAVES;       // (the dg jobs above sit on the low waves)
             if (job < nAt) {
               const int mt = job / ntn, nt = job - mt * ntn;
               const int vcl = min(mt * 16 + l16, N - 1), wcl = min(nt * 16 + l16, N - 1);
               // dA[v][w] += sum_j x1[v][j] dx2[w][j] + g[v][j] dx1[w][j]:  k = j = (t, c), eight contiguous c per lane
               for (int t = 0; t < T; ++t) {
-                float av[8], bv[8];
-                sg_ld8(x1 + g.nrow(vcl, t) * 32 + 8 * q, av); sg_ld8(dx2 + g.nrow(wcl, t) * 32 + 8 * q, bv);
+                float a0[8], b0[8], a1[8], b1[8];
+                sg_ld8(x1 + g.nrow(vcl, t) * 32 + 8 * q, a0); sg_ld8(dx2 + g.nrow(wcl, t) * 32 + 8 * q, b0);
+                sg_ld8(gl + g.nrow(vcl, t) * ldg + 8 * q, a1); sg_ld8(dx1 + g.nrow(wcl, t) * 32 + 8 * q, b1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) accA[s] = SG_MFMA(av[j], bv[j], accA[s]);
-                sg_ld8(gl + g.nrow(vcl, t) * ldg + 8 * q, av); sg_ld8(dx1 + g.nrow(wcl, t) * 32 + 8 * q, bv);
+                for (int j = 0; j < 8; ++j) accA[s] = SG_MFMA(a0[j], b0[j], accA[s]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) accA[s] = SG_MFMA(av[j], bv[j], accA[s]);
+                for (int j = 0; j < 8; ++j) accA[s] = SG_MFMA(a1[j], b1[j], accA[s]);
               }
             }
           }
@@ -521,7 +607,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
       }
     } else {
       // last layer: only the skip path reaches g
-      for (int pl = tr; pl < P; pl += 32) { const long r = g.row(pl); a.dg[r * 32 + tc] = a.dgskip[r * ldg + li * 32 + tc]; }
+      for (int pl = tr; pl < P; pl += SG_NR) { const long r = g.row(pl); a.dg[r * 32 + tc] = a.dgskip[r * ldg + li * 32 + tc]; }
       if (tid < 32) { slab[SG_S_GA + tid] = 0.f; slab[SG_S_BE + tid] = 0.f; slab[SG_S_BM + tid] = 0.f; }
       for (int i = tid; i < 32 * 32 * (1 + 2 * a.nsup); i += SG_THREADS) slab[SG_S_WM + i] = 0.f;
       __syncthreads();
@@ -529,30 +615,37 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
 
     // ---- T1: recompute the pre-activations, form their gradients
     float sb[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int job = wave; job < mtiles * 2; job += SG_WAVES) {
-      const int mt = job >> 1, nh = job & 1;
+    for (int mt = wave; mt < mtiles; mt += SG_WAVES) {
       const int pl = min(mt * 16 + l16, P - 1);
       float av[8];
       sg_ld8(xin + g.row(pl) * 32 + 8 * q, av);
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] = av[j] * aff[8 * q + j] + aff[32 + 8 * q + j];
-      sg_f4 af = {0.f, 0.f, 0.f, 0.f}, ag = af;
+      float dgv[2][4];
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dgv[nh][i] = a.dg[g.row(min(mt * 16 + 4 * q + i, P - 1)) * 32 + nh * 16 + l16];
+      sg_f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        af = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + nh * 16 + l16], af);
-        ag = SG_MFMA(av[j], wt[(8 * q + j) * SG_LDW + 32 + nh * 16 + l16], ag);
-      }
-      const int c = nh * 16 + l16;
+        const float* wr = wt + (8 * q + j) * SG_LDW + l16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int po = mt * 16 + 4 * q + i;
-        if (po < P) {
-          const long ro = g.row(po);
-          const float th = sg_tanh(af[i] + bias[c]), sg = sg_sigmoid(ag[i] + bias[32 + c]);
-          const float dgv = a.dg[ro * 32 + c];
-          const float df = dgv * sg * (1.f - th * th), dgt = dgv * th * sg * (1.f - sg);
-          a.dpre[ro * 64 + c] = df; a.dpre[ro * 64 + 32 + c] = dgt;
-          sb[nh][0] += df; sb[nh][1] += dgt;
+        for (int u = 0; u < 4; ++u) acc[u] = SG_MFMA(av[j], wr[16 * u], acc[u]);
+      }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const int c = nh * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int po = mt * 16 + 4 * q + i;
+          if (po < P) {
+            const long ro = g.row(po);
+            const float th = sg_tanh(acc[nh][i] + bias[c]), sg = sg_sigmoid(acc[2 + nh][i] + bias[32 + c]);
+            const float df = dgv[nh][i] * sg * (1.f - th * th), dgt = dgv[nh][i] * th * sg * (1.f - sg);
+            a.dpre[ro * 64 + c] = df; a.dpre[ro * 64 + 32 + c] = dgt;
+            sb[nh][0] += df; sb[nh][1] += dgt;
+          }
         }
       }
     }
@@ -572,46 +665,43 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
     }
     // ---- T2: du = dpre @ [Wf; Wg] (+ dh through the residual) -> gradient w.r.t. the layer input (before its
     //      BatchNorm affine); weight gradients of the two convs: dW[c][ci] = sum_p dpre[p][c] xin[p][ci]
-    {
-      const int njd = mtiles * 2, njw = 4 * 2;
-      for (int job = wave; job < njd + njw; job += SG_WAVES) {
-        if (job < njd) {
-          const int mt = job >> 1, nh = job & 1;
-          const int pl = min(mt * 16 + l16, P - 1);
-          const long r = g.row(pl);
-          sg_f4 acc = sg_tile(2,
-              [&](int kc, float* av) { sg_ld8(a.dpre + r * 64 + kc * 32 + 8 * q, av); },
-              [&](int kc, float* bv) {
+    for (int mt = wave; mt < mtiles; mt += SG_WAVES) {
+      const int pl = min(mt * 16 + l16, P - 1);
+      const long r = g.row(pl);
+      float av[2][8];
+      sg_ld8(a.dpre + r * 64 + 8 * q, av[0]); sg_ld8(a.dpre + r * 64 + 32 + 8 * q, av[1]);
+      float dhv[2][4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bv[j] = wtn[(kc * 32 + 8 * q + j) * SG_LDM + nh * 16 + l16];
-              });
-          const int c = nh * 16 + l16;
+      for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int po = mt * 16 + 4 * q + i;
-            if (po < P) {
-              const long ro = g.row(po);
-              a.dxo[ro * 32 + c] = acc[i] + (has_dh ? a.dh[ro * 32 + c] : 0.f);
-            }
-          }
-        } else {
-          const int jw = job - njd, ct = jw >> 1, nh = jw & 1;          // rows c of [Wf; Wg] (64), columns ci (32)
-          const int cr = ct * 16 + l16, ci = nh * 16 + l16;
-          sg_f4 acc = sg_tile((P + 31) >> 5,
-              [&](int kc, float* av) {
+        for (int i = 0; i < 4; ++i)
+          dhv[nh][i] = has_dh ? a.dh[g.row(min(mt * 16 + 4 * q + i, P - 1)) * 32 + nh * 16 + l16] : 0.f;
+      sg_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const int pl = kc * 32 + 8 * q + j; av[j] = pl < P ? a.dpre[g.row(pl) * 64 + cr] : 0.f; }
-              },
-              [&](int kc, float* bv) {
+      for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const int pl = min(kc * 32 + 8 * q + j, P - 1); bv[j] = xin[g.row(pl) * 32 + ci] * aff[ci] + aff[32 + ci]; }
-              });
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int c = ct * 16 + 4 * q + i;
-            slab[(c < 32 ? SG_S_WF + c * 32 : SG_S_WG + (c - 32) * 32) + ci] = acc[i];
-          }
+        for (int j = 0; j < 8; ++j) {
+          const float* wr = wtn + (kc * 32 + 8 * q + j) * SG_LDM + l16;
+          acc[0] = SG_MFMA(av[kc][j], wr[0], acc[0]); acc[1] = SG_MFMA(av[kc][j], wr[16], acc[1]);
         }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int po = mt * 16 + 4 * q + i;
+          if (po < P) a.dxo[g.row(po) * 32 + nh * 16 + l16] = acc[nh][i] + dhv[nh][i];
+        }
+    }
+    for (int jw = wrot; jw < 8; jw += SG_WAVES) {
+      const int ct = jw >> 1, nh = jw & 1;          // rows c of [Wf; Wg] (64), columns ci (32)
+      const int cr = ct * 16 + l16, ci = nh * 16 + l16;
+      const float sc = aff[ci], sh = aff[32 + ci];
+      // (rows past the tensor read 0 from dpre, so the affine of the 0 read from xin there is multiplied away)
+      const sg_f4 acc = wtile(a.dpre, 64, cr, xin, 32, ci, [&](float v, long) { return v; }, [&](float v) { return v * sc + sh; });
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = ct * 16 + 4 * q + i;
+        slab[(c < 32 ? SG_S_WF + c * 32 : SG_S_WG + (c - 32) * 32) + ci] = acc[i];
       }
     }
     __syncthreads();
@@ -620,8 +710,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
   if (nAt) {
     float* dA = a.dA + (long)blockIdx.x * N * N;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int job = wave + s * SG_WAVES;
+    for (int s = 0; s < 3; ++s) {
+      const int job = ((wave_ + 6) % SG_WAVES) + s * SG_WAVES;
       if (job < nAt) {
         const int mt = job / ntn, nt = job - mt * ntn;
 #pragma unroll
@@ -678,7 +768,7 @@ static size_t sg_bwd_lds(int N, int ndense) {
 }
 extern "C" int mo_gwnet_small_supported(int N, int T, int L, int nsup, int ndense) {
   if (N < 1 || T < 1 || L < 1 || L > SG_MAXL || nsup < 0 || nsup > SG_MAXS || ndense < 0 || ndense > nsup) return 0;
-  if ((long)N * T > 8192 || N > 80) return 0;      // (the adaptive support's gradient: <= 32 tiles of 16 x 16, two per wave)
+  if ((long)N * T > 8192 || N > 80) return 0;      // (the adaptive support's gradient: <= 25 tiles of 16 x 16, three per wave)
   return sg_bwd_lds(N, ndense) <= 160 * 1024 && sg_fwd_lds(N, ndense) <= 160 * 1024;
 }
 extern "C" long mo_gwnet_small_slab_floats(int nsup) { return sg_slab_floats(nsup); }
@@ -716,11 +806,19 @@ extern "C" int mo_gwnet_small_fwd(int B, int N, int T, int L, int nsup, const in
   const size_t lds = sg_fwd_lds(N, a.ndense);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)sg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)sg_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MO_ELAUNCH;
+    const void* ks[] = {(const void*)sg_fwd_kernel<0>, (const void*)sg_fwd_kernel<1>, (const void*)sg_fwd_kernel<2>,
+                        (const void*)sg_fwd_kernel<3>, (const void*)sg_bwd_kernel<0>, (const void*)sg_bwd_kernel<1>,
+                        (const void*)sg_bwd_kernel<2>, (const void*)sg_bwd_kernel<3>};
+    for (const void* k : ks)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MO_ELAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(sg_fwd_kernel, dim3(B), dim3(SG_THREADS), lds, st, a);
+  switch (a.ndense) {
+    case 0: hipLaunchKernelGGL(sg_fwd_kernel<0>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+    case 1: hipLaunchKernelGGL(sg_fwd_kernel<1>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(sg_fwd_kernel<2>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+    default: hipLaunchKernelGGL(sg_fwd_kernel<3>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+  }
   if (training) hipLaunchKernelGGL(sg_running_kernel, dim3(L), dim3(32), 0, st, a, momentum);
   return mo_launch_status();
 }
@@ -747,7 +845,13 @@ extern "C" int mo_gwnet_small_bwd(int B, int N, int T, int L, int nsup, const in
   if (adaptive_dense >= 0) { dAs = w; w += (long)B * N * N; }
   a.dA = dAs;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sg_bwd_kernel, dim3(B), dim3(SG_THREADS), sg_bwd_lds(N, a.ndense), st, a);
+  const size_t lds = sg_bwd_lds(N, a.ndense);
+  switch (a.ndense) {
+    case 0: hipLaunchKernelGGL(sg_bwd_kernel<0>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+    case 1: hipLaunchKernelGGL(sg_bwd_kernel<1>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(sg_bwd_kernel<2>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+    default: hipLaunchKernelGGL(sg_bwd_kernel<3>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
+  }
   SgReduceArgs r = {};
   for (int i = 0; i < L; ++i) {
     void* const* p = dsts + (long)i * 8;
