@@ -354,7 +354,9 @@ def test_modified_unet_follows_the_reference_training_trajectory(name, mode, tol
             noise = float(np.linalg.norm(G['p64/' + k] - want)) / moved
             dn = float(np.quantile(np.abs(G['p64/' + k] - want), 0.98))
         assert d <= max(2.5e-3, 2.0 * dn), (k, d, dn)
-        lim = (max(5e-2, 3.0 * noise) if mode == 'f32' else max(0.6, 3.0 * noise))
+        # (config 3's golden has no float64 run -- 20 minutes of CPU per step there: a flat 0.2 for the fp32 mode, whose
+        #  noise-dominated first-layer weights sit at 0.08)
+        lim = ((max(5e-2, 3.0 * noise) if 'p64/' + k in G.files else 0.2) if mode == 'f32' else max(0.6, 3.0 * noise))
         assert rel <= lim, (k, rel, noise)
         if rel > worst[0]:
             worst = (rel, k, noise)
