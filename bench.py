@@ -262,6 +262,11 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
         loss = step()
         ev[i + 1].record()
         host[i + 1] = time.perf_counter() - t0
+        if i >= 2:
+            # the launch thread is ~2x faster than the GPU here: left alone it runs many steps ahead, blocks freed on the
+            # weight-gradient lane are still pending when the next steps allocate, and the caching allocator grows with
+            # hipMalloc calls inside the pass (14 in 10 steps).  Two steps of lead keep the GPU fed and the pool stable.
+            ev[i - 1].synchronize()
     sync()
     dt = time.perf_counter() - t0
     ms1 = torch.cuda.memory_stats()

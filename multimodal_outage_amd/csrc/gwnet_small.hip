@@ -112,7 +112,12 @@ __device__ __forceinline__ void sg_ld8(const float* p, float* a) {
 // dynamic LDS: adj [ndense][N][LDA] | wt [32][SG_LDW] (filter|gate, k-major) | wm [32 ne][SG_LDM] (k-major) | biases etc.
 // A wave's job is a strip of 16 rows with ALL its output columns (the A operand is loaded once) and every global load of a
 // job is issued before the first MFMA: a phase costs one L2 round trip, not one per 32-wide k chunk.
-template <int ND>
+// LR (LDS-resident): when N*T is small enough (134 positions at H = 2: 19 KB per [P][32] tensor) the layer input, the gated
+// output and the hops are MIRRORED in LDS and every read of a tensor produced inside the kernel comes from there -- a
+// dependent access through L2 costs ~2 us on this chip and a layer has five of them; the global copies (saved for
+// backward) are write-only here.
+#define SG_LDP 36          // LDS row stride of a mirrored [P][32] tensor (144 B: 16-byte aligned rows, bank-spread)
+template <int ND, bool LR>
 __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NE = 1 + 2 * ND;
@@ -125,6 +130,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
   float* bias = wm + 32 * NE * SG_LDM;          // bf[32] bg[32] bm[32]
   float* aff = bias + 96;                        // scale[32] shift[32] of the layer input
   float* part = aff + 64;                        // [SG_WAVES][64] BatchNorm partial sums
+  float* mir = part + SG_WAVES * 64;             // LR: XL[2] | GL | X1L[ND] X2L[ND] ...  each [P][SG_LDP]
+  const int MS = a.P * SG_LDP;
   SgGeo g; g.B = a.B; g.T = T; g.P = P; g.N = N; g.b = blockIdx.x;
   const long rows = a.rows;
   const int ldg = 32 * a.L;
@@ -132,6 +139,12 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
     for (int i = tid; i < N * N; i += SG_THREADS) adj_s[(d * N + i / N) * LDA + i % N] = a.adj[d][i];
   const int mtiles = (P + 15) >> 4;
   const int ntn = (N + 15) >> 4, kch = (N + 31) >> 5;     // N <= 80: kch <= 3
+  if (LR) {
+    for (int i = tid; i < P * 8; i += SG_THREADS) {       // the call's rows of h0 -> XL[0]
+      const int pl = i >> 3, c4 = (i & 7) * 4;
+      *reinterpret_cast<float4*>(mir + pl * SG_LDP + c4) = *reinterpret_cast<const float4*>(a.h0 + g.row(pl) * 32 + c4);
+    }
+  }
 
   for (int li = 0; li < a.L; ++li) {
     const SgLayer& Ly = a.ly[li];
@@ -158,12 +171,15 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
     __syncthreads();
     const float* xin = li == 0 ? a.h0 : a.hs + (long)(li - 1) * rows * 32;
     float* gout = a.gcat + li * 32;
+    float* XLc = mir + (li & 1) * MS;             // LR mirrors: this layer's input, the next layer's input, g, hops
+    float* XLn = mir + ((li & 1) ^ 1) * MS;
+    float* GL = mir + 2 * MS;
 
     // ---- A: gated TCN (kernel_size 1: two 1x1 convs)  g = tanh(Wf x + bf) * sigmoid(Wg x + bg)
     for (int mt = wave; mt < mtiles; mt += SG_WAVES) {
       const int pl = min(mt * 16 + l16, P - 1);
       float av[8];
-      sg_ld8(xin + g.row(pl) * 32 + 8 * q, av);
+      sg_ld8(LR ? XLc + pl * SG_LDP + 8 * q : xin + g.row(pl) * 32 + 8 * q, av);
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] = av[j] * aff[8 * q + j] + aff[32 + 8 * q + j];
       sg_f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -179,7 +195,11 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int po = mt * 16 + 4 * q + i;
-          if (po < P) gout[g.row(po) * ldg + c] = sg_tanh(acc[nh][i] + bias[c]) * sg_sigmoid(acc[2 + nh][i] + bias[32 + c]);
+          if (po < P) {
+            const float gv = sg_tanh(acc[nh][i] + bias[c]) * sg_sigmoid(acc[2 + nh][i] + bias[32 + c]);
+            gout[g.row(po) * ldg + c] = gv;
+            if (LR) GL[po * SG_LDP + c] = gv;
+          }
         }
       }
     }
@@ -199,12 +219,18 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
         const __amdgpu_buffer_rsrc_t rs = sg_rsrc(src, (rows * lds_ - (hop == 0 ? li * 32 : 0)) * 4);
         const int voff = (int)((g.nrow(8 * q, tt) * lds_ + l16) * 4), sstep = a.B * T * lds_ * 4;
         float bv[3][2][8];
+        const float* ML = hop == 0 ? GL : mir + (3 + 2 * d) * MS;       // LR: the hop's input mirror
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc)
           if (kc < kch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              bv[kc][0][j] = sg_bl(rs, voff, (kc * 32 + j) * sstep); bv[kc][1][j] = sg_bl(rs, voff + 64, (kc * 32 + j) * sstep);
+              if (LR) {
+                const float* r = ML + (min(kc * 32 + 8 * q + j, N - 1) * T + tt) * SG_LDP + l16;
+                bv[kc][0][j] = r[0]; bv[kc][1][j] = r[16];
+              } else {
+                bv[kc][0][j] = sg_bl(rs, voff, (kc * 32 + j) * sstep); bv[kc][1][j] = sg_bl(rs, voff + 64, (kc * 32 + j) * sstep);
+              }
             }
           }
         sg_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -221,7 +247,10 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int w = mt * 16 + 4 * q + i;
-          if (w < N) { float* o = dst + g.nrow(w, tt) * 32 + l16; o[0] = acc0[i]; o[16] = acc1[i]; }
+          if (w < N) {
+            float* o = dst + g.nrow(w, tt) * 32 + l16; o[0] = acc0[i]; o[16] = acc1[i];
+            if (LR) { float* m = mir + (3 + 2 * d + hop) * MS + (w * T + tt) * SG_LDP + l16; m[0] = acc0[i]; m[16] = acc1[i]; }
+          }
         }
       }
       __syncthreads();
@@ -237,7 +266,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
       float av[NE][8];
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
-        const float* s = e == 0 ? gout + r * ldg : a.xs + (((long)li * ND) * 2 + (e - 1)) * rows * 32 + r * 32;
+        const float* s = LR ? mir + (2 + e) * MS + pl * SG_LDP
+                            : (e == 0 ? gout + r * ldg : a.xs + (((long)li * ND) * 2 + (e - 1)) * rows * 32 + r * 32);
         sg_ld8(s + 8 * q, av[e]);
       }
       sg_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -258,8 +288,9 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
             const long ro = g.row(po);
             float v = acc[nh][i] + bias[64 + c];
             if (a.thresh) v = mo_hash32(lseed, (uint32_t)(ro * 32 + c)) < a.thresh ? 0.f : v * a.dscale;
-            v += xin[ro * 32 + c] * aff[c] + aff[32 + c];
+            v += (LR ? XLc[po * SG_LDP + c] : xin[ro * 32 + c]) * aff[c] + aff[32 + c];
             hout[ro * 32 + c] = v;
+            if (LR) XLn[po * SG_LDP + c] = v;
             s1[nh] += v; s2[nh] += v * v;
           }
         }
@@ -761,6 +792,7 @@ static size_t sg_fwd_lds(int N, int ndense) {
   const int ne = 1 + 2 * ndense;
   return sizeof(float) * ((size_t)ndense * N * sg_lda(N) + 32 * SG_LDW + 32 * ne * SG_LDM + 96 + 64 + SG_WAVES * 64);
 }
+static size_t sg_fwd_mirrors(int P, int ndense) { return sizeof(float) * (size_t)(3 + 2 * ndense) * P * SG_LDP; }
 static size_t sg_bwd_lds(int N, int ndense) {
   const int ne = 1 + 2 * ndense;
   return sizeof(float) * ((size_t)ndense * N * sg_lda(N) + 32 * SG_LDW + 64 * SG_LDM + 32 * (32 * ne + 2) + 64 + 64 + 160) +
@@ -803,22 +835,22 @@ extern "C" int mo_gwnet_small_fwd(int B, int N, int T, int L, int nsup, const in
   a.h0 = h0; a.gcat = gcat; a.hs = hs; a.xs = xs; a.stats = stats; a.training = training; a.eps = eps;
   a.seed = seed; a.thresh = training ? thresh : 0; a.dscale = dscale;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = sg_fwd_lds(N, a.ndense);
+  const bool lr = sg_fwd_lds(N, a.ndense) + sg_fwd_mirrors(a.P, a.ndense) <= 160 * 1024;
+  const size_t lds = sg_fwd_lds(N, a.ndense) + (lr ? sg_fwd_mirrors(a.P, a.ndense) : 0);
   static bool attr = false;
   if (!attr) {
-    const void* ks[] = {(const void*)sg_fwd_kernel<0>, (const void*)sg_fwd_kernel<1>, (const void*)sg_fwd_kernel<2>,
-                        (const void*)sg_fwd_kernel<3>, (const void*)sg_bwd_kernel<0>, (const void*)sg_bwd_kernel<1>,
+    const void* ks[] = {(const void*)sg_fwd_kernel<0, false>, (const void*)sg_fwd_kernel<1, false>, (const void*)sg_fwd_kernel<2, false>,
+                        (const void*)sg_fwd_kernel<3, false>, (const void*)sg_fwd_kernel<0, true>, (const void*)sg_fwd_kernel<1, true>,
+                        (const void*)sg_fwd_kernel<2, true>, (const void*)sg_fwd_kernel<3, true>, (const void*)sg_bwd_kernel<0>, (const void*)sg_bwd_kernel<1>,
                         (const void*)sg_bwd_kernel<2>, (const void*)sg_bwd_kernel<3>};
     for (const void* k : ks)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MO_ELAUNCH;
     attr = true;
   }
-  switch (a.ndense) {
-    case 0: hipLaunchKernelGGL(sg_fwd_kernel<0>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
-    case 1: hipLaunchKernelGGL(sg_fwd_kernel<1>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
-    case 2: hipLaunchKernelGGL(sg_fwd_kernel<2>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
-    default: hipLaunchKernelGGL(sg_fwd_kernel<3>, dim3(B), dim3(SG_THREADS), lds, st, a); break;
-  }
+#define SG_FWD(ND) do { if (lr) hipLaunchKernelGGL((sg_fwd_kernel<ND, true>), dim3(B), dim3(SG_THREADS), lds, st, a); \
+                        else hipLaunchKernelGGL((sg_fwd_kernel<ND, false>), dim3(B), dim3(SG_THREADS), lds, st, a); } while (0)
+  switch (a.ndense) { case 0: SG_FWD(0); break; case 1: SG_FWD(1); break; case 2: SG_FWD(2); break; default: SG_FWD(3); break; }
+#undef SG_FWD
   if (training) hipLaunchKernelGGL(sg_running_kernel, dim3(L), dim3(32), 0, st, a, momentum);
   return mo_launch_status();
 }

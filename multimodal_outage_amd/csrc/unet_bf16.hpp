@@ -298,8 +298,10 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     if (k + PF < nstage) issue_loads(k + PF, slotc);      // (this stage's registers are free again)
     if (k + 1 < nstage && (k + 1) % SPI == 0 && (img + 1) % a.gsize == 0) load_affine(img + 1);   // (every reader of aff is past the barrier)
     if (a.bfo) matrix_phase(UbBool<true>{}, img, tx, b); else matrix_phase(UbBool<false>{}, img, tx, b);
-    if (b == NBI - 1) {
-      if (a.stats) {                                      // per-tile BatchNorm statistics from the accumulators
+    if (b == NBI - 1 && tx == tiles_x - 1) {              // the band of this image is complete
+      if (a.stats) {                                      // per-BAND BatchNorm statistics from the accumulators (one row
+                                                          // per image and 16-row band: the finalize kernel walks 4x fewer
+                                                          // rows than with one per tile)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           float t1 = s1[nb], t2 = s2[nb];
@@ -309,8 +311,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
         }
         __syncthreads();
         if (tid < 32 * NB && (tid >> 1) < a.Co) {
-          const long ntile = (long)gridDim.x * tiles_x;
-          a.stats[((img * ntile + (long)blockIdx.x * tiles_x + tx) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
+          a.stats[((img * (long)gridDim.x + (long)blockIdx.x) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
               (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         }
       }

@@ -187,7 +187,7 @@ extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd);
 static bool ub_views_ok(int C0, int C1) { return C1 == 0 || (C0 == C1 && (C0 == 4 || C0 == 8 || C0 == 16)); }
 extern "C" int mo_conv3x3_stats_tiles2(int C0, int C1, int Co, long n_img, int H, int Wd, int dtypes) {
   if ((dtypes & MO_BF_MATH) && ub_views_ok(C0, C1) && mo_conv3x3_bf16_route(C0 + C1, Co, n_img, H, Wd))
-    return (Wd / ub_tw(Wd)) * (H / UB_TH);
+    return H / UB_TH;                                   // one statistics row per image and 16-row band
   return mo_conv3x3_stats_tiles(Co, n_img, H, Wd);
 }
 template <int CP, int RB, int TW = UB_TW>
