@@ -18,7 +18,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define MO_MAX_SEG 8
+#define MO_MAX_SEG 12     // column segments of a virtual operand: 1 + 2 x 5 supports + 1 (graph_wavenet.py:79: (order*support_len+1)*c_in)
 #define MO_KROWS 0
 #define MO_XROWS 1
 

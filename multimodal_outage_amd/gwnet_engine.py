@@ -329,7 +329,8 @@ class GwnetFunction(torch.autograd.Function):
             adpT = _e(N, N, dev)
             L.call('mo_adp_fwd', L.ptr(p['nodevec1']), L.ptr(p['nodevec2']), N, p['nodevec1'].shape[1],
                    L.ptr(adp), L.ptr(adpT), st)
-        use_bf = bool(cfg.dense_bf16 and adp is not None and N % 8 == 0)
+        # (more than 3 supports = more than 7 mlp sources: the tile engine serves them, in fp32 storage only)
+        use_bf = bool(cfg.dense_bf16 and adp is not None and N % 8 == 0 and 2 * (len(statics) + 1) + 1 <= 7)
         adp_bf = adpT_bf = None
         if use_bf:
             adp_bf, adpT_bf = _bf16_padded(adp), _bf16_padded(adpT)

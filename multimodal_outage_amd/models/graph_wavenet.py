@@ -212,8 +212,8 @@ class gwnet(nn.Module):
         key = device
         if self._statics is None or self._statics_dev != key:
             sup = self.supports if self._use_gcn() else []
-            if len(sup) * 2 + (2 if self.addaptadj else 0) + 1 > 8:
-                raise NotImplementedError('HIP gcn mlp supports at most 3 supports (incl. adaptive)')
+            if len(sup) * 2 + (2 if self.addaptadj else 0) + 1 > 11:
+                raise NotImplementedError('HIP gcn mlp serves at most 5 supports (incl. adaptive): 11 column segments')
             order = None
             if len(sup) > 0:
                 from ..gwnet_engine import cluster_order

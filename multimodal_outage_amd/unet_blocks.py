@@ -86,16 +86,23 @@ class UpFn(torch.autograd.Function):
         dev = x1.device
         gs = cfg.gsize or n
         C0 = Ci // 2
-        if tuple(x2.shape[2:]) != (2 * H, 2 * W):
-            raise NotImplementedError('Up: the F.pad of unet.py:76-81 (skip map larger than the upsampled one) is not on '
-                                      'the HIP path; it never triggers for even image sizes')
+        H2, W2 = x2.shape[2], x2.shape[3]
         u = _empty(n, C0, 2 * H, 2 * W, dev=dev)
         L.call('mo_convt2x2_fwd', L.ptr(x1), Ci * H * W, Ci, None, None, 0, gs, L.ptr(p[cfg.pre + '.up.weight']),
                L.ptr(p[cfg.pre + '.up.bias']), C0, n, H, W, L.ptr(u), C0 * 4 * H * W, L.stream())
-        sv, v = double_conv_fwd(p, cfg.pre + '.conv', [View(x2, x2.shape[1], 2 * H, 2 * W), View(u, C0, 2 * H, 2 * W)],
+        pad = None
+        if (H2, W2) != (2 * H, 2 * W):
+            # unet.py:76-81: the upsampled map is zero-padded (or cropped: F.pad takes negative widths) to the skip map's
+            # size.  Never reached inside Modified_UNET for image sizes that are multiples of 16; here it is a
+            # materialised copy of the small upsampled map (torch), the convs then run on the skip map's size
+            dY, dX = H2 - 2 * H, W2 - 2 * W
+            pad = [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2]
+            u = torch.nn.functional.pad(u, pad).contiguous()
+        sv, v = double_conv_fwd(p, cfg.pre + '.conv', [View(x2, x2.shape[1], H2, W2), View(u, C0, H2, W2)],
                                 cfg.Co, n, gs, cfg.training, cfg.bufs, dev)
         out = _materialise(v, n, gs)
         ctx.cfg, ctx.p, ctx.sv, ctx.n, ctx.gs, ctx.x1, ctx.dims = cfg, p, sv, n, gs, x1, (Ci, C0, H, W, x2.shape[1])
+        ctx.pad = pad
         return out
 
     @staticmethod
@@ -110,6 +117,9 @@ class UpFn(torch.autograd.Function):
         dx2 = dcat[:, :C2].contiguous()
         du = dcat[:, C2:]
         dus = dcat.stride(0)
+        if ctx.pad is not None:                          # backward of F.pad: the un-padded window (negative pad = crop)
+            du = torch.nn.functional.pad(du, [-v_ for v_ in ctx.pad]).contiguous()
+            dus = du.stride(0)
         Wt = p[cfg.pre + '.up.weight']
         dWt = grads.buf(cfg.pre + '.up.weight', Wt.shape)
         ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Ci, 4 * C0, n * H * W), n * C0 * 2), device=dev,

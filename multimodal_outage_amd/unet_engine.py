@@ -453,7 +453,9 @@ class UnetDecodeFn(torch.autograd.Function):
                    L.ptr(u), (ci // 2) * 4 * H * H, st)
             sk = skips[4 - k]
             if sk.H != 2 * H:
-                raise NotImplementedError('Up padding (unet.py:76-81) is only needed for odd sizes')
+                raise NotImplementedError('Up padding (unet.py:76-81) inside Modified_UNET: only reached by image sizes that '
+                                          'are not multiples of 16, whose odd widths the conv kernels (W % 4 == 0) do '
+                                          'not serve; the stand-alone Up block pads (unet_blocks.UpFn)')
             # bf16 mode: y1 of an Up block and the last block's y2 (read by OutConv's streaming kernels); the y2 of up1..3
             # feeds the next ConvTranspose2d, which runs on the fp32 tile engine, and stays fp32 (as does u)
             bk = bf_ok(state.get('act_dtype', 'f32'), co, 2 * H, 2 * H)

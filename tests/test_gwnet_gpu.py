@@ -304,6 +304,9 @@ VARIANTS = {
     'gwnet_V_nogcn': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=230, gcn_bool=False, addaptadj=True),
     'gwnet_V_static': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=240, gcn_bool=True, addaptadj=False),
     'gwnet_V_k1': dict(B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, seed=250, gcn_bool=True, addaptadj=True),
+    # more than three supports: 3 / 4 static + adaptive = 9 / 11 mlp sources, served by the tile engine
+    'gwnet_V_s4': dict(B=2, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=260, gcn_bool=True, addaptadj=True, nstatic=3),
+    'gwnet_V_s5': dict(B=2, N=20, T=6, in_dim=5, out_dim=2, K=2, seed=270, gcn_bool=True, addaptadj=True, nstatic=4),
 }
 
 
@@ -314,11 +317,12 @@ def test_gwnet_constructor_variants_vs_golden(name):
     cfg = VARIANTS[name]
     G = golden(name)
     A = P.knn_graph(20)
-    sup = [gwnet_ref.asym_adj(A), gwnet_ref.asym_adj(A.T)]
+    B2 = P.knn_graph(20, seed=11)
+    sup = [gwnet_ref.asym_adj(A), gwnet_ref.asym_adj(A.T), gwnet_ref.asym_adj(B2), gwnet_ref.asym_adj(B2.T)][:cfg.get('nstatic', 2)]
     adaptive = cfg['gcn_bool'] and cfg['addaptadj']
     m = gwnet('cpu', num_nodes=20, dropout=0.0, supports=sup, in_dim=cfg['in_dim'], out_dim=cfg['out_dim'],
               kernel_size=cfg['K'], gcn_bool=cfg['gcn_bool'], addaptadj=cfg['addaptadj'])
-    schema = P.gwnet_schema(num_nodes=20, supports_len=2 + (1 if adaptive else 0), in_dim=cfg['in_dim'],
+    schema = P.gwnet_schema(num_nodes=20, supports_len=len(sup) + (1 if adaptive else 0), in_dim=cfg['in_dim'],
                             out_dim=cfg['out_dim'], kernel_size=cfg['K'], gcn_bool=cfg['gcn_bool'],
                             addaptadj=cfg['addaptadj'])
     P.load_into(m, P.seeded_values(schema, cfg['seed']))

@@ -249,6 +249,8 @@ VARIANTS = {
     'gwnet_V_nogcn': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=230, gcn_bool=False, addaptadj=True),
     'gwnet_V_static': dict(B=3, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=240, gcn_bool=True, addaptadj=False),
     'gwnet_V_k1': dict(B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, seed=250, gcn_bool=True, addaptadj=True),
+    'gwnet_V_s4': dict(B=2, N=20, T=12, in_dim=3, out_dim=4, K=2, seed=260, gcn_bool=True, addaptadj=True, nstatic=3),
+    'gwnet_V_s5': dict(B=2, N=20, T=6, in_dim=5, out_dim=2, K=2, seed=270, gcn_bool=True, addaptadj=True, nstatic=4),
 }
 
 
@@ -258,9 +260,10 @@ def test_gwnet_constructor_variants(name):
     cfg = VARIANTS[name]
     G = golden(name)
     A = P.knn_graph(20)
-    sup = [torch.from_numpy(gwnet_ref.asym_adj(A)), torch.from_numpy(gwnet_ref.asym_adj(A.T))]
+    B2 = P.knn_graph(20, seed=11)
+    sup = [torch.from_numpy(gwnet_ref.asym_adj(m_)) for m_ in (A, A.T, B2, B2.T)][:cfg.get('nstatic', 2)]
     adaptive = cfg['gcn_bool'] and cfg['addaptadj']
-    schema = P.gwnet_schema(num_nodes=20, supports_len=2 + (1 if adaptive else 0), in_dim=cfg['in_dim'],
+    schema = P.gwnet_schema(num_nodes=20, supports_len=len(sup) + (1 if adaptive else 0), in_dim=cfg['in_dim'],
                             out_dim=cfg['out_dim'], kernel_size=cfg['K'], gcn_bool=cfg['gcn_bool'],
                             addaptadj=cfg['addaptadj'])
     p = P.as_param_dict(P.seeded_values(schema, cfg['seed']))

@@ -149,3 +149,33 @@ def test_contraction_encoder_decoder_expansion_forward():
         for k in G.files:
             if k.startswith(nm + '/buf/'):
                 assert_close(sd[k[len(nm) + 5:]].float(), G[k], 1e-5, 1e-4, k)
+
+
+@pytest.mark.parametrize('nm,skip_shape', [('pad_sym', (2, 8, 16, 20)), ('pad_asym', (2, 8, 15, 20))])
+def test_up_pad_branch(nm, skip_shape):
+    """Up.forward's F.pad branch (unet.py:76-81): a skip map larger than the upsampled one, symmetric (2,2,2,2) and
+    asymmetric (top 1 / bottom 2) zero padding, against the reference's own Up class body (tests/golden/unet_up_pad.npz):
+    output, loss, both input gradients, every parameter gradient, BatchNorm buffers."""
+    from multimodal_outage_amd.models.unet import Up
+    G = golden('unet_up_pad')
+    seed = int(G['seed'])
+    m = Up(16, 8)
+    P.load_into(m, P.seeded_values({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed))
+    m = m.cuda().train()
+    a = rand(seed + 10, (2, 16, 6, 8)).cuda().requires_grad_(True)
+    b = rand(seed + 11, skip_shape).cuda().requires_grad_(True)
+    y = m(a, b)
+    assert tuple(y.shape) == (2, 8) + skip_shape[2:]
+    assert_close(y, G[nm + '/y'], 1e-4, 1e-4, nm + ' y')
+    loss = F.mse_loss(y, rand(seed + 20, tuple(y.shape)).cuda())
+    assert abs(loss.item() - float(G[nm + '/loss'])) < 1e-5
+    loss.backward()
+    for i, t in enumerate((a, b)):
+        assert_close(t.grad, G[f'{nm}/dx{i}'], 1e-6, 1e-3, f'{nm} dx{i}')
+    for k, v in m.named_parameters():
+        ref = G[f'{nm}/grad/{k}']
+        assert_close(v.grad, ref, 1e-4 * float(np.abs(ref).max()) + 1e-7, 1e-3, f'{nm} grad {k}')
+    sd = m.state_dict()
+    for k in G.files:
+        if k.startswith(nm + '/buf/'):
+            assert_close(sd[k[len(nm) + 5:]].float(), G[k], 1e-5, 1e-4, k)

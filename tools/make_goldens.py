@@ -162,6 +162,34 @@ def unet_blocks_case(seed=300):
     print('unet_blocks done')
 
 
+def up_pad_case(seed=340):
+    """Up.forward's F.pad branch (unet.py:76-81): skip maps larger than the upsampled map, symmetric and asymmetric
+    padding -- the reference's own Up class body, tiny shapes (widths stay multiples of 4, what the conv kernels serve)."""
+    ns_g = R.load_gwnet(False, [torch.eye(67)])
+    ns = R.load_unet(ns_g['gwnet'])
+    d = {}
+    for nm, shapes in (('pad_sym', [(2, 16, 6, 8), (2, 8, 16, 20)]), ('pad_asym', [(2, 16, 6, 8), (2, 8, 15, 20)])):
+        torch.manual_seed(0)
+        m = ns['Up'](16, 8)
+        P.load_into(m, P.seeded_values({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed))
+        m.train()
+        ins = [rand(seed + 10 + i, s).requires_grad_(True) for i, s in enumerate(shapes)]
+        y = m(*ins)
+        loss = F.mse_loss(y, rand(seed + 20, tuple(y.shape)))
+        loss.backward()
+        d[nm + '/y'] = y.detach().numpy()
+        d[nm + '/loss'] = np.float64(loss.item())
+        for i, t in enumerate(ins):
+            d[f'{nm}/dx{i}'] = t.grad.numpy()
+        for k, prm in m.named_parameters():
+            d[f'{nm}/grad/{k}'] = prm.grad.numpy()
+        for k, v in buffers(m).items():
+            d[f'{nm}/{k}'] = v
+    d['seed'] = np.int64(seed)
+    np.savez_compressed(os.path.join(OUT, 'unet_up_pad.npz'), **d)
+    print('unet_up_pad done')
+
+
 def modified_unet_case(name, B, H, seed, channels=1, size=128):
     """Modified_UNET fwd + MSE + bwd through the reference's own class bodies (unet.py:201-231); `size` is the
     module global image_dimension the reference's Encoder/Decoder read (unet.py:132-136,156-160), `channels` its
@@ -478,6 +506,16 @@ if __name__ == '__main__':
                    seed=240, addaptadj=False)
         gwnet_case('gwnet_V_k1', B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, static_supports=sup2, generic=True,
                    seed=250)
+    if 'up_pad' in which:
+        up_pad_case()
+    if 'variants2' in which:
+        # more than three supports (graph_wavenet.py:124-134: supports_len = len(supports) + 1): 4 and 5 supports in all
+        A20 = P.knn_graph(20)
+        B20 = P.knn_graph(20, seed=11)
+        sup3 = [asym_adj(A20), asym_adj(A20.T), asym_adj(B20)]
+        gwnet_case('gwnet_V_s4', B=2, N=20, T=12, in_dim=3, out_dim=4, K=2, static_supports=sup3, generic=True, seed=260)
+        gwnet_case('gwnet_V_s5', B=2, N=20, T=6, in_dim=5, out_dim=2, K=2, static_supports=sup3 + [asym_adj(B20.T)],
+                   generic=True, seed=270)
     if 'ckpt' in which:
         checkpoint_case()
     if 'blocks' in which:
