@@ -98,3 +98,22 @@ def test_cosine_lr_matches_cosine_annealing_lr():
         assert abs(cosine_lr(1e-3, e) - want) < 1e-12 and abs(live - want) < 1e-15, (e, cosine_lr(1e-3, e), want)
         o.step()
         s.step()
+
+
+def _samp(t):
+    a = t.detach().float().cpu().numpy().reshape(-1)
+    return a[::max(1, a.size // 256)][:256]
+
+
+def test_full_model_constructor_consumes_rng_like_the_reference():
+    """Row f2, full model: under the same torch.manual_seed the product's Modified_UNET constructor yields the reference
+    constructor's initial values for ALL 254 state_dict tensors (tests/golden/unet_ckpt.npz holds a strided sample of each:
+    unet.py:202-217 -> Contraction, Encoder, gwnet, Decoder, Expansion created in the same order with the same RNG use)."""
+    from multimodal_outage_amd.models.unet import Modified_UNET
+    G = golden('unet_ckpt')
+    torch.manual_seed(int(G['seed']))
+    m = Modified_UNET('gwnet', 2, input_channels=1, output_channels=1)
+    sd = m.state_dict()
+    assert [str(k) for k in G['keys']] == list(sd.keys()) and len(sd) == 254
+    for k, v in sd.items():
+        assert np.array_equal(_samp(v), G['init/' + k]), k

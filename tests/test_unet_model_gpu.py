@@ -447,3 +447,86 @@ def test_training_step_fused_loss_equals_the_two_step_form(mode):
     for k, g in res[False][2].items():
         d = float((res[True][2][k] - g).norm()) / max(float(g.norm()), 1e-30)
         assert d <= (1e-5 if mode == 'f32' else 2e-2), (k, d)
+
+
+def test_full_model_lightning_checkpoint_resume():
+    """Row f2 for the FULL model (lit.py:59-72,187-196).  tests/golden/unet_ckpt.npz: the reference's
+    Modified_UNET default-initialised under torch.manual_seed, 3 steps of Adam(1e-3) + one CosineAnnealingLR epoch, strided
+    samples of all 254 tensors / of Adam's moments, and the 4th step.  The product (fp32 mode) starts from the same seed
+    (its constructor reproduces the init values, tests/test_checkpoint_cpu.py), runs the three steps -> weights and Adam
+    state agree with the reference's samples; checkpoint.lightning_state writes the Lightning-shaped dict (`model.*`, 254
+    tensors, optimizer_states, lr_schedulers); a FRESH model + trainer loads it with load_lightning_state and the resumed
+    4th step reproduces the reference's loss (1e-4) and parameters."""
+    from multimodal_outage_amd.models.unet import Modified_UNET
+    from multimodal_outage_amd.trainer import FlatTrainer
+    from multimodal_outage_amd.checkpoint import lightning_state, load_lightning_state
+    G = golden('unet_ckpt')
+    seed = int(G['seed'])
+
+    def fresh(s):
+        torch.manual_seed(s)
+        m = Modified_UNET('gwnet', 2, input_channels=1, output_channels=1)
+        m.st_gnn.dropout = 0.0
+        m.encoder.dropout1.p = 0.0
+        m.decoder.dropout1.p = 0.0
+        return m.cuda().train()
+
+    def step(m, tr, i):
+        x = rand(seed + 10 + i, (1, 67, 2, 1, 128, 128)).cuda()
+        td = rand(seed + 40 + i, (1, 67, 2, 64)).cuda()
+        tgt = rand(seed + 70 + i, (1, 67, 2, 1, 128, 128)).cuda()
+        tr.zero_grad()
+        loss = F.mse_loss(m(x, td), tgt)
+        loss.backward()
+        tr.allreduce()
+        tr.step()
+        return float(loss)
+
+    m = fresh(seed)
+    tr = FlatTrainer(m, lr=1e-3).attach()
+    losses = [step(m, tr, i) for i in range(3)]
+    for a, b in zip(losses, G['losses']):
+        assert abs(a - b) <= 1e-4 * abs(b), (losses, list(G['losses']))
+    # weights / buffers / Adam state after three steps against the reference's samples
+    sd = m.state_dict()
+    for k, v in sd.items():
+        ref = G['sd/' + k]
+        if 'num_batches' in k:
+            assert np.array_equal(_sample256(v), ref), k
+        elif 'running_' in k:
+            # (activation statistics of weights that already differ by Adam's sign noise on near-zero gradients)
+            assert float(np.abs(_sample256(v) - ref).max()) <= 1e-2 + 1e-2 * float(np.abs(ref).max()), k
+        else:
+            assert float(np.quantile(np.abs(_sample256(v) - ref), 0.98)) <= 2.5e-3 + 1e-3 * float(np.abs(ref).max()), k
+    ck = lightning_state(m, tr, prefix='model.', epoch=1)
+    assert len(ck['state_dict']) == 254 and all(k.startswith('model.') for k in ck['state_dict'])
+    names = [k for k, _ in m.named_parameters()]
+    has = G['opt/has_state']
+    gmax = max(float(np.abs(G['opt/exp_avg/' + k]).max()) for i, k in enumerate(names) if has[i])
+    for i, k in enumerate(names):
+        st = ck['optimizer_states'][0]['state'][i]
+        if has[i]:
+            ref = G['opt/exp_avg/' + k]
+            sc = max(float(np.abs(ref).max()), 1e-4 * gmax)      # (tensors whose whole gradient is at the noise floor)
+            # (first moments = averaged gradients: the deep stages' are sums with heavy cancellation, two fp32 evaluations
+            #  sit up to ~10 % of a small tensor's scale apart, DESIGN 4)
+            assert float(np.quantile(np.abs(_sample256(st['exp_avg']) - ref), 0.98)) <= 0.25 * sc, k
+        else:
+            assert float(st['exp_avg'].abs().max()) == 0.0, k
+    # a fresh model (other seed) + trainer load the checkpoint and resume
+    m2 = fresh(seed + 999)
+    tr2 = FlatTrainer(m2, lr=1e-3).attach()
+    info = load_lightning_state(ck, m2, tr2, prefix='model.')
+    assert info['optimizer'] and info['step'] == 3 and info['last_epoch'] == 1 and info['tensors'] == 254
+    assert abs(tr2.lr - float(G['opt/lr'])) < 1e-12
+    assert torch.equal(tr2.flat_p, tr.flat_p) and torch.equal(tr2.m, tr.m) and torch.equal(tr2.v, tr.v)
+    l4 = step(m2, tr2, 3)
+    assert abs(l4 - float(G['loss4'])) <= 1e-4 * float(G['loss4']), (l4, float(G['loss4']))
+    for k, v in m2.named_parameters():
+        ref = G['p4/' + k]
+        assert float(np.quantile(np.abs(_sample256(v) - ref), 0.98)) <= 3.5e-3 + 1e-3 * float(np.abs(ref).max()), k
+
+
+def _sample256(t):
+    a = t.detach().float().cpu().numpy().reshape(-1)
+    return a[::max(1, a.size // 256)][:256]

@@ -433,6 +433,65 @@ def checkpoint_case(name='gwnet_ckpt', seed=1234):
     print(name, 'loss4', l4, 'lr', d['opt/lr'])
 
 
+def checkpoint_unet_case(name='unet_ckpt', seed=4321, H=2, size=128):
+    """Row f2 for the FULL model (lit.py:59-72,187-196): the reference's Modified_UNET, default-initialised under
+    torch.manual_seed (pins the constructor's RNG consumption for all 254 tensors), 3 steps of Adam(1e-3) + one
+    CosineAnnealingLR(T_max=10) epoch; strided samples of every state_dict tensor at init and after step 3, of Adam's
+    exp_avg / exp_avg_sq, the scheduler's state, and the 4th step's loss + parameter samples a resumed run must
+    reproduce.  (The whole state is 113 MB: the fixture keeps samples, the test regenerates the state by running the
+    same three steps and checks it against these samples before it saves / loads / resumes.)"""
+    sup = [torch.eye(67)]
+    ns_g = R.load_gwnet(False, sup)
+    ns = R.load_unet(ns_g['gwnet'], image_dimension=size)
+    torch.manual_seed(seed)
+    m = ns['Modified_UNET'](st_gnn='gwnet', horizon=H, input_channels=1, output_channels=1)
+    m.st_gnn.dropout = 0.0
+    for g in m.st_gnn.gconv:
+        g.dropout = 0.0
+    m.encoder.dropout1.p = 0.0
+    m.decoder.dropout1.p = 0.0
+    m.train()
+
+    def samp(t):
+        a = t.detach().numpy().reshape(-1)
+        return a[::max(1, a.size // 256)][:256].copy()
+
+    d = {'seed': np.int64(seed), 'keys': np.array(list(m.state_dict().keys()))}
+    for k, v in m.state_dict().items():
+        d['init/' + k] = samp(v.float())
+    names = [k for k, _ in m.named_parameters()]
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
+
+    def step(i):
+        x = rand(seed + 10 + i, (1, 67, H, 1, size, size))
+        td = rand(seed + 40 + i, (1, 67, H, 64))
+        tgt = rand(seed + 70 + i, (1, 67, H, 1, size, size))
+        opt.zero_grad(set_to_none=True)
+        loss = F.mse_loss(m(x, td), tgt)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    d['losses'] = np.array([step(i) for i in range(3)], dtype=np.float64)
+    sched.step()
+    for k, v in m.state_dict().items():
+        d['sd/' + k] = samp(v.float())
+    osd = opt.state_dict()
+    d['opt/lr'] = np.float64(osd['param_groups'][0]['lr'])
+    d['opt/has_state'] = np.array([int(i in osd['state']) for i in range(len(names))])
+    for i, k in enumerate(names):
+        if i in osd['state']:
+            d['opt/exp_avg/' + k] = samp(osd['state'][i]['exp_avg'])
+            d['opt/exp_avg_sq/' + k] = samp(osd['state'][i]['exp_avg_sq'])
+    d['sched/last_epoch'] = np.int64(sched.state_dict()['last_epoch'])
+    d['loss4'] = np.float64(step(3))
+    for k, v in m.named_parameters():
+        d['p4/' + k] = samp(v)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'losses', d['losses'], 'loss4', d['loss4'], 'lr', d['opt/lr'])
+
+
 def csr_case():
     import pandas as pd
     import scipy.sparse as sp
@@ -506,6 +565,8 @@ if __name__ == '__main__':
                    seed=240, addaptadj=False)
         gwnet_case('gwnet_V_k1', B=2, N=20, T=7, in_dim=6, out_dim=5, K=1, static_supports=sup2, generic=True,
                    seed=250)
+    if 'ckpt_unet' in which:
+        checkpoint_unet_case()
     if 'up_pad' in which:
         up_pad_case()
     if 'variants2' in which:
