@@ -228,7 +228,7 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
     lit = LitModified_UNET('gwnet', horizon, dev, input_channels=cin, output_channels=cin, image_dimension=size)
     m = lit.model.train()
     m.act_dtype = act_dtype      # BASELINE config 3 names bf16 (storage + matrix-pipe arithmetic)
-    tr = FlatTrainer(m).attach()
+    tr = FlatTrainer(m, eager_adam=True).attach()      # Adam of a module as soon as its gradients are final (trainer.py)
     g = torch.Generator().manual_seed(2000 + int(os.environ.get('RANK', '0')))
     x = torch.randn(batch, horizon, 67, cin, size, size, generator=g).to(dev)
     y = torch.randn(batch, horizon, 67, cin, size, size, generator=g).to(dev)

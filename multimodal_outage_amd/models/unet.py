@@ -247,7 +247,7 @@ class Modified_UNET(nn.Module):
         # through autograd.
         state = dict(gsize=H, training=self.training, bufs=bufs,
                      fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None),
-                     act_dtype=getattr(self, 'act_dtype', 'f32'))
+                     act_dtype=getattr(self, 'act_dtype', 'f32'), adam_now=getattr(self, '_mo_adam_now', None))
         st_e = dict(state, names=enc_names)
         x_off = self._image_offsets(input, n) if input.dtype == torch.float32 else False
         if x_off is None or x_off is False or S < 32 or S % 4 or Cin > 32:
@@ -265,6 +265,7 @@ class Modified_UNET(nn.Module):
         if getattr(self.st_gnn, 'forward_calls', None) is not None:
             self.st_gnn._mo_grad_out = getattr(self, '_mo_grad_out_st_gnn', None)
             z = self.st_gnn.forward_calls(o).reshape(n, feature_vector_size)
+            st_e['st_gnn_in_place'] = self.st_gnn._mo_grad_out is not None
         else:
             z = torch.stack([self.st_gnn(o[b]) for b in range(B)]).reshape(n, feature_vector_size)
         st_d = dict(state, names=dec_names, skip_meta=st_e['skip_meta'],

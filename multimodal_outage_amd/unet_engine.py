@@ -414,6 +414,12 @@ class UnetEncodeFn(torch.autograd.Function):
         saved = [dict(sv, y2=outs[1 + k]) if k < 4 else sv for k, sv in enumerate(saved)]
         lane = _Lane(dev)
         dx5a = fc_block_bwd(p, fc_sv, dfeat, grads, lane=lane)
+        if state.get('adam_now') is not None and state.get('grad_out'):
+            # a flat-buffer trainer in eager mode: the FC bottleneck's and the Graph WaveNet's gradients are final (the
+            # decoder side's were announced at the end of its backward) -- their Adam update goes on the weight-gradient
+            # lane now and runs beside the contraction's backward
+            pre = ('encoder.', 'st_gnn.') if state.get('st_gnn_in_place') else ('encoder.',)
+            lane.run(lambda ls: state['adam_now'](pre, ls))
         v5 = saved[4]
         dp = double_conv_bwd(p, saved[4], n, gs, grads, dev, da=dx5a.view(n, v5['Co'], v5['H'], v5['W']), dp=None,
                              dx_bf=bool(saved[4]['views'][0].bf), lane=lane)
@@ -557,5 +563,7 @@ class UnetDecodeFn(torch.autograd.Function):
             da = _empty(n, ci, H, H, dev=dev)
             L.call('mo_convt2x2_bwd_data', du.data_ptr(), du_stride, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
         dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads, lane=lane)
+        if state.get('adam_now') is not None and state.get('grad_out'):
+            lane.run(lambda ls: state['adam_now'](('decoder.', 'expansion.'), ls))      # (eager Adam, see UnetEncodeFn.backward)
         lane.join()
         return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(state['names'])

@@ -35,7 +35,7 @@ def main():
     lit.fused_loss = not a.two_step
     m = lit.model.train()
     m.act_dtype = a.dtype
-    tr = FlatTrainer(m).attach()
+    tr = FlatTrainer(m, eager_adam=True).attach()      # Adam of a module as soon as its gradients are final (trainer.py)
     B, H, S = a.batch, a.horizon, a.size
     x = torch.randn(B, H, 67, a.cin, S, S, device='cuda')        # the DataLoader's layout (utils.py:101-105)
     y = torch.randn(B, H, 67, a.cin, S, S, device='cuda')
