@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
   const __amdgpu_buffer_rsrc_t rh = ub_rsrc(a.ah, (long)a.P * a.R * 2), rl = ub_rsrc(a.al, (long)a.P * a.R * 2);
   const __amdgpu_buffer_rsrc_t rw = ub_rsrc(a.W, (long)a.R * a.C * 4);
 
+  // More rows than 16 * MB (several windows per step): row groups of 16 * MB, one after the other INSIDE the workgroup -- its
+  // weight panel (64 columns x its share of the reduction, ~256 KB) is then re-read from L2 / the Infinity Cache instead of
+  // the whole 268 MB matrix being streamed from HBM once per group by separate launches.
+  const int ngroups = (a.P + ROWS - 1) / ROWS;
+  for (int rg = 0; rg < ngroups; ++rg) {
+  const int prow = rg * ROWS;
   ub_f4 acc[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
     const int row = i / (UFC_KC / 8), seg = i - row * (UFC_KC / 8);
     const bool ok = i < ROWS * (UFC_KC / 8);
     xdst[it] = ok ? row * UFC_LD + 8 * seg : -1;
-    xsrc[it] = (ok && row < a.P) ? row * a.R + 8 * seg : -1;
+    xsrc[it] = (ok && row + prow < a.P) ? (row + prow) * a.R + 8 * seg : -1;
   }
   auto load_chunk = [&](const int ch) {
     const long r0 = r_begin + (long)ch * UFC_KC;
@@ -152,9 +158,11 @@ __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int p = mb * 16 + 4 * lg + r;
+        const int p = prow + mb * 16 + 4 * lg + r;
         if (p < a.P) out[(long)p * a.C + c0 + lp] = acc[mb][r];
       }
+  }
+  __syncthreads();                                                         // (the next group restages the LDS operand)
   }
 }
 

@@ -244,22 +244,16 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
 # (A plain bf16 product was measured too: 0.3 ms faster still, but it moved the deep-stage gradient distance of the config-3
 # golden from 0.69 to 0.78 -- the 3-way split leaves it where it was.)
 FC3_MIN = (1 << 22) if os.environ.get('MO_FC3', '1') != '0' else (1 << 62)
-FC3_ROWS = 134                                            # rows per chunk (<= 144: csrc/unet_fc.hpp UFC_MB)
 
 
 def _fc_fwd(x, W, b, relu, math=False):
     P, Ci = x.shape
     Co = W.shape[0]
     out = _empty(P, Co, dev=x.device)
-    if math and W.numel() >= FC3_MIN and L.load().mo_fc3_supported(min(P, FC3_ROWS), Ci, Co):
-        # the 3 x bf16 kernels serve <= 144 rows (one window of 67 counties x 2 days): more windows per step go through
-        # them in row chunks -- the weight matrix is streamed once per chunk (268 MB, ~60 us), still 2.5x faster than the
-        # exact-fp32 tile engine, which is compute bound on these products
-        for r0 in range(0, P, FC3_ROWS):
-            r1 = min(P, r0 + FC3_ROWS)
-            ws = torch.empty(L.load().mo_fc3_ws_floats(r1 - r0, Ci, Co), device=x.device, dtype=torch.float32)
-            L.call('mo_fc3_fwd', x[r0:r1].data_ptr(), r1 - r0, Ci, L.ptr(W), L.ptr(b), Co, 1 if relu else 0,
-                   out[r0:r1].data_ptr(), L.ptr(ws), L.stream())
+    if math and W.numel() >= FC3_MIN and L.load().mo_fc3_supported(P, Ci, Co):
+        # (more rows than one window's 134: the kernel walks row groups of 144 itself, its weight panel re-read from L2)
+        ws = torch.empty(L.load().mo_fc3_ws_floats(P, Ci, Co), device=x.device, dtype=torch.float32)
+        L.call('mo_fc3_fwd', L.ptr(x), P, Ci, L.ptr(W), L.ptr(b), Co, 1 if relu else 0, L.ptr(out), L.ptr(ws), L.stream())
         return out
     if Ci >= 2048 and P <= 1024:        # few rows x long K: split-K (the tile grid alone would be ~20 workgroups)
         ws = torch.empty(L.load().mo_linear_splitk_ws_floats(P, Co, Ci), device=x.device, dtype=torch.float32)
@@ -314,12 +308,9 @@ def fc_block_bwd(p, sv, dh2, grads, need_input_grad=True, lane=None):
         if not need_in:
             return None
         din = _empty(P, Ci, dev=dev)
-        if sv.get('math') and W.numel() >= FC3_MIN and lib.mo_fc3_supported(min(P, FC3_ROWS), Co, Ci):
-            for r0 in range(0, P, FC3_ROWS):                 # (row chunks, as the forward)
-                r1 = min(P, r0 + FC3_ROWS)
-                wsd = torch.empty(lib.mo_fc3_ws_floats(r1 - r0, Co, Ci), device=dev, dtype=torch.float32)
-                L.call('mo_fc3_bwd_data', dout[r0:r1].data_ptr(), r1 - r0, Co, L.ptr(W), Ci, din[r0:r1].data_ptr(),
-                       L.ptr(wsd), st)
+        if sv.get('math') and W.numel() >= FC3_MIN and lib.mo_fc3_supported(P, Co, Ci):
+            wsd = torch.empty(lib.mo_fc3_ws_floats(P, Co, Ci), device=dev, dtype=torch.float32)
+            L.call('mo_fc3_bwd_data', L.ptr(dout), P, Co, L.ptr(W), Ci, L.ptr(din), L.ptr(wsd), st)
             return din
         if Co >= 2048 and P <= 1024:
             wsd = torch.empty(lib.mo_linear_splitk_ws_floats(P, Ci, Co), device=dev, dtype=torch.float32)

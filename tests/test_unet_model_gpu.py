@@ -353,7 +353,9 @@ def test_modified_unet_follows_the_reference_training_trajectory(name, mode, tol
         if 'p64/' + k in G.files:
             noise = float(np.linalg.norm(G['p64/' + k] - want)) / moved
             dn = float(np.quantile(np.abs(G['p64/' + k] - want), 0.98))
-        assert d <= max(2.5e-3, 2.0 * dn), (k, d, dn)
+        # (without a float64 run -- config 3 -- 5e-3: on the 128x128 trajectory the reference's own fp32-vs-float64 98th
+        #  percentile is 2.3e-3 .. 3.0e-3 for the Graph WaveNet's weights, whose gradients are at the noise floor)
+        assert d <= (max(2.5e-3, 2.0 * dn) if 'p64/' + k in G.files else 5e-3), (k, d, dn)
         # (config 3's golden has no float64 run -- 20 minutes of CPU per step there: a flat 0.35 for the fp32 mode; its
         #  noise-dominated tensors -- the first conv, the deep encoder stages whose gradients are 1e-8 -- sit at 0.08..0.23,
         #  as the reference's own fp32-vs-float64 distance does on the 128x128 trajectory)

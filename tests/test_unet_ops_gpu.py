@@ -313,7 +313,9 @@ def test_dropout_mask(L):
     assert torch.equal(y, y2)
 
 
-@pytest.mark.parametrize('P,K,N', [(134, 16384, 4096), (134, 1024, 16384), (7, 256, 128), (144, 4096, 264), (33, 520, 72)])
+@pytest.mark.parametrize('P,K,N', [(134, 16384, 4096), (134, 1024, 16384), (7, 256, 128), (144, 4096, 264), (33, 520, 72),
+                                   # several windows per step: row groups of 144 walked inside the kernel (ragged last group)
+                                   (536, 16384, 4096), (300, 1024, 520), (145, 256, 128)])
 def test_fc_three_way_bf16_split(L, P, K, N):
     """mo_fc3_fwd / mo_fc3_bwd_data (csrc/unet_fc.hpp): few-row Linear layers with "3 x bf16" split products on the bf16
     matrix pipe against the float64 product: 5e-5 of the result's scale (a plain bf16 product would sit at ~2e-3);
@@ -333,6 +335,8 @@ def test_fc_three_way_bf16_split(L, P, K, N):
     ws = torch.empty(lib.mo_fc3_ws_floats(P, N, K), device='cuda')
     L.call('mo_fc3_bwd_data', L.ptr(dd), P, N, L.ptr(Wd), K, L.ptr(din), L.ptr(ws), L.stream())
     close(din, dout.double() @ W.double(), tol=5e-5, what='fc3 data gradient')
+    if P > 160:
+        return                                   # (the weight-gradient kernel serves one window: P <= 160 rows)
     dW = torch.full((N, K), float('nan'), device='cuda'); db = torch.full((N,), float('nan'), device='cuda')
     ws = torch.empty(lib.mo_fc3_wgrad_ws_floats(P, N, K), device='cuda')
     L.call('mo_fc3_bwd_weight', L.ptr(dd), P, N, L.ptr(xd), K, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
