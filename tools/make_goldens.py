@@ -594,7 +594,7 @@ if __name__ == '__main__':
     if 'traj_unet' in which:
         unet_trajectory_case('traj_unet_B1H2', B=1, H=2, seed=610)
     if 'traj_unet_c3' in which:
-        unet_trajectory_case('traj_unet_C3', B=1, H=2, seed=620, channels=13, size=256, with_f64=False)
+        unet_trajectory_case('traj_unet_C3', B=1, H=2, seed=620, channels=13, size=256, with_f64=True)
     if 'unet_h7' in which:
         unet_conditioned_grad_case()
     if 'unet_c3' in which:
