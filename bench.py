@@ -217,7 +217,7 @@ def cpu_baseline(supports, max_steps=5, batch=4, budget_s=25.0):
             "gpu_loss_same_steps": gpu_matched_loss(schema, supports, x, y, steps + 1)}
 
 
-def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=256, act_dtype='bf16'):
+def unet_leg(world, dev, steps=10, warmup=12, batch=1, horizon=2, cin=13, size=256, act_dtype='bf16'):
     """Secondary metric of BASELINE.json ("+ UNet tiles/sec"): Modified_UNET training step (forward + MSE/metrics +
     backward + all-reduce + Adam) on synthetic (B,67,H,13,256,256) GOES-style tiles (config 3), batch-sharded
     like the gwnet leg.  Returns the object printed under "unet"."""
@@ -250,8 +250,8 @@ def unet_leg(world, dev, steps=10, warmup=3, batch=1, horizon=2, cin=13, size=25
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        step()
+    for _ in range(warmup):                 # (the caching allocator's pool settles after ~10 steps of this leg: the gwnet leg
+        step()                              #  before it returned its memory to the driver)
     sync()
     # ONE timed pass; every step also gets a host timestamp and a HIP event, so that a stall shows where it sits
     # (launch side vs device side, which step) instead of disappearing in a best-of-N
@@ -472,12 +472,32 @@ def main():
     L.call = real_call
     prof_serial, engine.PROFILE = engine.PROFILE, None
     engine.SERIAL = False
+    # ... and the same per-launch events with the step's real stream structure (dA products and the weight-gradient lane
+    # beside the main chain): the block's kernels as they run INSIDE the step, stretched by what shares the chip with them
+    per_call_in = []
+
+    def timed_call_in(name, *a):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_call(name, *a)
+        e1.record()
+        per_call_in.append((name, e0, e1))
+    L.call = timed_call_in
+    for _ in range(n_serial):
+        step()
+    sync()
+    L.call = real_call
+    by_name_in = {}
+    for name, e0, e1 in per_call_in:
+        by_name_in[name] = by_name_in.get(name, 0.0) + e0.elapsed_time(e1) / n_serial
     by_name = {}
     for name, e0, e1 in per_call:
         by_name[name] = by_name.get(name, 0.0) + e0.elapsed_time(e1) / n_serial
     BLOCK = ('mo_tcn_fwd', 'mo_tcn_bwd', 'mo_tcn_pack_weights', 'mo_spmm_blk', 'mo_spmm_csr', 'mo_gcn_mlp_fwd',
              'mo_gcn_mlp_bwd', 'mo_bn_finalize', 'mo_bn_bwd')
     block_ms = sum(by_name.get(k, 0.0) for k in BLOCK)
+    block_ms_in = sum(by_name_in.get(k, 0.0) for k in BLOCK)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -527,6 +547,12 @@ def main():
                  "algorithmic_GB_per_step": round(blk_gb, 3), "kernel_ms_per_step": round(block_ms, 3),
                  "achieved": round(blk_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                  "frac": round(blk_ach / PEAK_HBM_GBPS, 4),
+                 "in_step": {"kernel_ms_per_step": round(block_ms_in, 3),
+                             "achieved": round(blk_gb / (block_ms_in * 1e-3), 1) if block_ms_in > 0 else 0.0,
+                             "frac": round(blk_gb / (block_ms_in * 1e-3) / PEAK_HBM_GBPS, 4) if block_ms_in > 0 else 0.0,
+                             "note": "the same launches timed inside steps with the real stream structure (the dA products "
+                                     "and the weight-gradient lane run beside them): HIP events around every launch on its "
+                                     "own stream, 2 extra steps"},
                  "kernel_ms": {k: round(v, 3) for k, v in sorted(by_name.items(), key=lambda kv: -kv[1])[:14]},
                  "whole_step": {"algorithmic_MB_per_window_fwd": round(stp_b / 1e6, 1),
                                 "algorithmic_GB_per_step": round(stp_gb, 3), "ms_per_step": round(step_ms, 3),
@@ -555,11 +581,17 @@ def main():
         # the per-step costs of that leg (FC bottleneck, Adam, the 67-node Graph WaveNet's launch chain) amortise with the
         # batch: the same step at 4 windows per GPU (536 tiles), reported beside the 1-window figure
         try:
-            u4 = unet_leg(world, dev, steps=5, warmup=2, batch=4)
+            u4 = unet_leg(world, dev, steps=5, warmup=6, batch=4)
             line["unet"]["at_4_windows_per_gpu"] = {"value": u4["value"], "unit": "tiles/s", "ms_per_step": u4["ms_per_step"],
                                                     "tiles_per_step_per_gpu": u4["tiles_per_step_per_gpu"]}
         except Exception as e:                            # (never lose the line to the extra measurement)
             line["unet"]["at_4_windows_per_gpu"] = {"error": repr(e)[:200]}
+        # the exact-fp32 mode of the same step (the mode the 1e-4 parity tests run), beside the bf16 headline
+        try:
+            uf = unet_leg(world, dev, steps=5, warmup=6, act_dtype='f32')
+            line["unet"]["f32_mode"] = {"value": uf["value"], "unit": "tiles/s", "ms_per_step": uf["ms_per_step"]}
+        except Exception as e:
+            line["unet"]["f32_mode"] = {"error": repr(e)[:200]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             print("[bench] gpu: " + json.dumps({k: line[k] for k in ("value", "ms_per_step", "loss")}), file=sys.stderr, flush=True)

@@ -9,9 +9,15 @@ m = lit.model.train(); m.act_dtype = 'bf16'
 tr = FlatTrainer(m).attach()
 x = torch.randn(B, 2, 67, 13, 256, 256, device='cuda'); y = torch.randn_like(x); td = torch.randn(B, 67, 2, 64, device='cuda')
 prev = 0
-for i in range(16):
+lead = int(sys.argv[2]) if len(sys.argv) > 2 else 0        # 0: synchronise every step; k: at most k steps of lead
+evs = []
+for i in range(40):
     tr.zero_grad(); loss = lit.training_step((x, y, td)); loss.backward(); tr.allreduce(); tr.step()
-    torch.cuda.synchronize()
+    evs.append(torch.cuda.Event()); evs[-1].record()
+    if lead == 0:
+        torch.cuda.synchronize()
+    elif i >= lead:
+        evs[i - lead].synchronize()
     s = torch.cuda.memory_stats()
     n = s.get('num_device_alloc', 0)
     print(i, 'allocs', n - prev, 'reserved MB', s['reserved_bytes.all.current'] >> 20, 'active MB', s['active_bytes.all.peak'] >> 20, 'gc', gc.get_count())
