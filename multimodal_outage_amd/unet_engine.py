@@ -14,6 +14,9 @@ import torch
 from . import _lib as L
 
 WGRAD_LANE = os.environ.get('MO_UNET_WGRAD_LANE', '1') != '0'     # A/B switch: weight gradients on a side stream
+# experiments on where the bf16 mode's deep-stage gradient error comes from (tests: modified_unet_H7 by stage)
+GRAD_F32 = os.environ.get('MO_UNET_GRAD_F32', '0') != '0'         # gradient tensors (dy, da, dx) stored fp32 in the bf16 mode
+DGRAD_F32 = os.environ.get('MO_UNET_DGRAD_F32', '0') != '0'       # data gradients on the exact-fp32 kernels in the bf16 mode
 
 
 class _Lane:
@@ -186,7 +189,7 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
     math = L.BF_MATH * int(sv.get('math', False))
 
     def act_bwd(y, aff, bnkey, da_t, dp_t, scale=None):
-        dy = _empty(n, Co, H, W, dev=dev, bf=_is_bf(y))          # the gradient of a conv output is stored as the output is
+        dy = _empty(n, Co, H, W, dev=dev, bf=_is_bf(y) and not GRAD_F32)    # the gradient of a conv output is stored as the output is
         dg = grads.buf(bnkey + '.weight', (Co,))
         db = grads.buf(bnkey + '.bias', (Co,))
         ws = torch.empty(lib.mo_unet_act_bwd_ws_floats(n, Co), device=dev, dtype=torch.float32)
@@ -214,9 +217,10 @@ def double_conv_bwd(p, sv, n, gs, grads, dev, da=None, dp=None, need_input_grad=
 
     def dgrad(dy, Wt, out_bf):
         Ci = Wt.shape[1]
+        out_bf = bool(out_bf) and not GRAD_F32
         dx = _empty(n, Ci, H, W, dev=dev, bf=out_bf)
         dt = (L.BF_IN0 * _is_bf(dy)) | (L.BF_OUT * int(out_bf))
-        if math and lib.mo_conv3x3_bf16_route(Co, Ci, n, H, W):
+        if math and not DGRAD_F32 and lib.mo_conv3x3_bf16_route(Co, Ci, n, H, W):
             # the bf16 matrix-pipe kernel reads the forward weights transposed + flipped in place
             L.call('mo_conv3x3_fwd', L.ptr(dy), Co, Co * HW, None, None, 0, *_NOVIEW, 1, L.ptr(Wt), Ci, n, H, W,
                    L.ptr(dx), Ci * HW, None, dt | math | L.W_FLIP, None, st)
@@ -470,12 +474,12 @@ class UnetDecodeFn(torch.autograd.Function):
             # training_step (lit.py:32-38): OutConv + MSE / MAE / MAPE + OutConv's data and weight gradient sums in one
             # pass; yhat and dL/dyhat are never written (mo_outc_loss_fwd)
             HW = v.H * v.W
-            da = _empty(n, v.C, v.H, v.W, dev=dev, bf=bool(v.bf))
+            da = _empty(n, v.C, v.H, v.W, dev=dev, bf=bool(v.bf) and not GRAD_F32)
             ws = torch.empty(L.load().mo_outc_loss_ws_floats(n, HW, v.C, Cout), device=dev, dtype=torch.float32)
             out4 = torch.empty(4, device=dev, dtype=torch.float32)
             L.call('mo_outc_loss_fwd', L.ptr(v.t), v.istride, v.C, L.ptr(v.sc), L.ptr(v.sh), 1, gs, L.ptr(Wo), L.ptr(bo),
                    Cout, tgt.data_ptr(), L.ptr(state.get('target_off')), n, HW, None, L.ptr(da), v.C * HW, L.ptr(ws),
-                   L.ptr(out4), (L.BF_IN0 * v.bf) | (L.BF_OUT * v.bf), st)
+                   L.ptr(out4), (L.BF_IN0 * v.bf) | (L.BF_OUT * _is_bf(da)), st)
             ctx.loss_da, ctx.loss_ws = da, ws
             return out4
         out = _empty(n, Cout, v.H, v.W, dev=dev)
@@ -509,9 +513,9 @@ class UnetDecodeFn(torch.autograd.Function):
             L.call('mo_nchw_conv1x1_bwd_weight', L.ptr(dout), Cout * HW, Cout, L.ptr(v.t), v.istride, C4, L.ptr(v.sc),
                    L.ptr(v.sh), 1, gs, n, HW, L.ptr(dWo), L.ptr(dbo), L.ptr(ws), L.BF_IN0 * v.bf, ls)
         lane.run(outc_wgrad, reads=[dout, v.t, v.sc, v.sh, dWo, dbo])
-        da = _empty(n, C4, v.H, v.W, dev=dev, bf=bool(v.bf))
+        da = _empty(n, C4, v.H, v.W, dev=dev, bf=bool(v.bf) and not GRAD_F32)
         L.call('mo_nchw_conv1x1_bwd_data', L.ptr(dout), Cout * HW, Cout, L.ptr(Wo), C4, n, HW, L.ptr(da), C4 * HW,
-               L.BF_OUT * v.bf, st)
+               L.BF_OUT * _is_bf(da), st)
         return UnetDecodeFn._backward_body(ctx, grads, lane, da, None, None, None)
 
     @staticmethod
