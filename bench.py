@@ -242,7 +242,7 @@ def unet_leg(world, dev, steps=10, warmup=12, batch=1, horizon=2, cin=13, size=2
         loss.backward()
         tr.allreduce()
         tr.step()
-        return loss
+        return loss.detach()       # (the graph behind `loss` holds the step's activations as Function attributes: do not keep it)
 
     def sync():
         torch.cuda.synchronize()
@@ -250,8 +250,13 @@ def unet_leg(world, dev, steps=10, warmup=12, batch=1, horizon=2, cin=13, size=2
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):                 # (the caching allocator's pool settles after ~10 steps of this leg: the gwnet leg
-        step()                              #  before it returned its memory to the driver)
+    wev = []
+    for i in range(warmup):                 # (the caching allocator's pool settles after ~10 steps of this leg -- the gwnet leg
+        step()                              #  before it returned its memory to the driver -- under the same two steps of
+        wev.append(torch.cuda.Event())      #  launch-thread lead as the timed pass below)
+        wev[-1].record()
+        if i >= 2:
+            wev[i - 2].synchronize()
     sync()
     # ONE timed pass; every step also gets a host timestamp and a HIP event, so that a stall shows where it sits
     # (launch side vs device side, which step) instead of disappearing in a best-of-N
@@ -264,6 +269,10 @@ def unet_leg(world, dev, steps=10, warmup=12, batch=1, horizon=2, cin=13, size=2
         loss = step()
         ev[i + 1].record()
         host[i + 1] = time.perf_counter() - t0
+        if os.environ.get('MO_BENCH_DEBUG'):
+            ms_ = torch.cuda.memory_stats()
+            print(f'[bench] unet step {i}: device allocs so far {ms_.get("num_device_alloc", 0)}, reserved '
+                  f'{ms_["reserved_bytes.all.current"] >> 20} MB, alloc retries {ms_.get("num_alloc_retries", 0)}', file=sys.stderr)
         if i >= 2:
             # the launch thread is ~2x faster than the GPU here: left alone it runs many steps ahead, blocks freed on the
             # weight-gradient lane are still pending when the next steps allocate, and the caching allocator grows with

@@ -747,6 +747,7 @@ class GwnetFunction(torch.autograd.Function):
         lane.join()
         if cfg.grad_ready is not None:
             cfg.grad_ready([n for n in cfg.names if n in gout and gout[n] is not None])
+        ctx.layers = ctx.x_int = ctx.adp = ctx.adpT = ctx.skip = ctx.r1 = ctx.adp_bf = ctx.W1_bf = ctx.skip_bf = None
         # gradients written straight into registered flat-buffer views are not handed to autograd
         return (None, None, None, None, None, dx) + tuple(
             None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)
@@ -955,5 +956,6 @@ class GwnetSmallFunction(torch.autograd.Function):
             grads['nodevec1'], grads['nodevec2'] = gE1, gE2
         if cfg.grad_ready is not None:
             cfg.grad_ready([n for n in cfg.names if n in gout and gout[n] is not None])
+        ctx.keep = None                               # (release the saved activations with the backward pass)
         return (None, None, None, None, dx) + tuple(
             None if (k in gout and gout[k] is not None) else grads[k] for k in cfg.names)

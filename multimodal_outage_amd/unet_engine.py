@@ -427,6 +427,8 @@ class UnetEncodeFn(torch.autograd.Function):
         lane.join()
         if dp is not None and ctx.x_shape is not None:
             dp = dp.view(ctx.x_shape)
+        # the step's activations hang on this node as attributes: release them now, not when the caller drops the loss
+        ctx.saved = ctx.fc_sv = None
         return (None, dp) + grads.result(state['names'])
 
 
@@ -561,4 +563,5 @@ class UnetDecodeFn(torch.autograd.Function):
         if state.get('adam_now') is not None and state.get('grad_out'):
             lane.run(lambda ls: state['adam_now'](('decoder.', 'expansion.'), ls))      # (eager Adam, see UnetEncodeFn.backward)
         lane.join()
+        ctx.fc_sv = ctx.ups = ctx.vlast = ctx.loss_da = ctx.loss_ws = None      # (release the activations, see UnetEncodeFn)
         return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(state['names'])

@@ -6,7 +6,7 @@ torch.manual_seed(42)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 lit = LitModified_UNET('gwnet', 2, 'cuda', input_channels=13, output_channels=13, image_dimension=256)
 m = lit.model.train(); m.act_dtype = 'bf16'
-tr = FlatTrainer(m).attach()
+tr = FlatTrainer(m, eager_adam=(len(sys.argv) > 3)).attach()
 x = torch.randn(B, 2, 67, 13, 256, 256, device='cuda'); y = torch.randn_like(x); td = torch.randn(B, 67, 2, 64, device='cuda')
 prev = 0
 lead = int(sys.argv[2]) if len(sys.argv) > 2 else 0        # 0: synchronise every step; k: at most k steps of lead

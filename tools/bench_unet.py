@@ -47,7 +47,7 @@ def main():
         loss.backward()
         tr.allreduce()
         tr.step()
-        return loss
+        return loss.detach()       # (the graph behind `loss` holds the step's activations as Function attributes: do not keep it)
 
     for _ in range(a.warmup):
         step()
