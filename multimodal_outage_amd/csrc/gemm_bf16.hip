@@ -8,6 +8,8 @@
 // 128x128x32 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_32x32x16_bf16, register-prefetched double
 // buffered LDS.  LDS rows are padded so that the ds_read_b128 fragment reads (80-byte rows) and the
 // transposing reads (320-byte rows) are bank-conflict free (MI355X_MICROARCH.md, LDS section).
+#include <cstdlib>
+#include <type_traits>
 #include "mo_common.h"
 #include "../../include/mo_hip.h"
 
@@ -15,6 +17,7 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
 
 #define GB_BM 128
@@ -268,7 +271,19 @@ __device__ __forceinline__ v4s g2_ldstr(uint32_t addr) {
 #define G2_ST 4
 #define G2_STAGE_SHORTS 16384   // 16 KB A + 16 KB B per stage, in bf16 elements
 
-template <bool B_KROWS>
+// MF16: the same tile on v_mfma_f32_16x16x32_bf16 (8 x 4 accumulator blocks of 16 x 16 per wave instead of 4 x 2 of
+// 32 x 32; an MFMA takes a whole 32-wide k-tile, so the software pipeline splits a k-tile by ROWS: blocks 0-3, then
+// 4-7, the B fragments double-buffered across k-tiles).  Same LDS bytes and MFMA cycles per k-tile; under the power
+// limit the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS item 7).  The fragment reads differ, so
+// the source swizzles do too: [x][64 B]: slot ^= {0,2,3,1}[(x>>2)&3]; [k][512 B]: slot16 ^= (k&3)<<2 | ((k>>3)&1)<<1.
+template <bool MF16> __device__ __forceinline__ int g2_swz_x(int x) {
+  const int rb = (x >> 2) & 3;
+  return MF16 ? ((0x78 >> (2 * rb)) & 3) : rb;
+}
+template <bool MF16> __device__ __forceinline__ int g2_swz_k(int k) {
+  return ((k & 3) << 2) | (MF16 ? (((k >> 3) & 1) << 1) : 0);
+}
+template <bool B_KROWS, bool MF16>
 __global__ void __launch_bounds__(512)
 gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restrict__ B, int ldb, float* __restrict__ D,
                      int ldd, int M, int N, int K, int beta, unsigned short* __restrict__ Dbf,
@@ -294,18 +309,18 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
     const int p = wave * 128 + i * 64 + lane;            // 16-byte slot index inside the 16 KB operand stage
     {
       const int x = p >> 2, pc = p & 3;
-      const int c = pc ^ ((x >> 2) & 3);
+      const int c = pc ^ g2_swz_x<MF16>(x);
       const int gr = min(m0 + x, M - 1);
       a_off[i] = (long)gr * lda + 8 * c;
     }
     if (B_KROWS) {
       const int kr = p >> 5, ph = p & 31;
-      const int lg = ph ^ ((kr & 3) << 2);
+      const int lg = ph ^ g2_swz_k<MF16>(kr);
       const int gc = min(n0 + 8 * lg, N - 8);
       b_off[i] = gc;                                      // + (k0 + kr) * ldb at issue time (row clamp)
     } else {
       const int x = p >> 2, pc = p & 3;
-      const int c = pc ^ ((x >> 2) & 3);
+      const int c = pc ^ g2_swz_x<MF16>(x);
       const int gr = min(n0 + x, N - 1);
       b_off[i] = (long)gr * ldb + 8 * c;
     }
@@ -331,19 +346,154 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
     }
   };
 
-  f32x16 acc[4][2];
+  constexpr int NI = MF16 ? 8 : 4, NJ = MF16 ? 4 : 2, NR = MF16 ? 4 : 16;   // accumulator blocks of the wave's 128 x 64
+  typedef typename std::conditional<MF16, f32x4, f32x16>::type acc_t;
+  acc_t acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (K + G2_BK - 1) / G2_BK;
   for (int s = 0; s < G2_ST - 1 && s < nk; ++s) issue(s);
 
   const int fr = lane & 31, fh = lane >> 5;
   const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  // accumulator element (i, j, r) -> row / column inside the wave's 128 x 64
+  auto erow = [&](int i, int r) { return MF16 ? i * 16 + 4 * tg + r : i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh; };
+  auto ecol = [&](int j) { return MF16 ? j * 16 + (lane & 15) : j * 32 + fr; };
+  if constexpr (MF16) {
+    uint32_t aA, aB[4];
+    {
+      const int x = wm0 + (lane & 15);                         // + 16 i rows = + 1024 i bytes (swizzle unchanged)
+      aA = lds_base + (uint32_t)(x * 64 + ((tg ^ g2_swz_x<true>(x)) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (B_KROWS) {
+          const int kr = 8 * tg + tq;                           // second read: + 4 k rows = + 2048 bytes
+          const int nc = wn0 + 16 * j + 4 * tp;
+          const int ph = (nc >> 3) ^ g2_swz_k<true>(kr);
+          aB[j] = lds_base + 16384u + (uint32_t)(2 * (kr * 256 + ph * 8 + (nc & 7)));
+        } else {
+          const int xb = wn0 + (lane & 15);                     // + 16 j rows = + 1024 j bytes
+          aB[j] = lds_base + 16384u + (uint32_t)(xb * 64 + ((tg ^ g2_swz_x<true>(xb)) << 4)) + 1024u * j;
+        }
+      }
+    }
+    auto rdAL = [&](int kt, v8s (&a)[4]) {                     // row blocks 0-3 of stage kt
+      const uint32_t pa = aA + (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+      a[0] = g2_lds128<0>(pa); a[1] = g2_lds128<1024>(pa); a[2] = g2_lds128<2048>(pa); a[3] = g2_lds128<3072>(pa);
+    };
+    auto rdAH = [&](int kt, v8s (&a)[4]) {                     // row blocks 4-7
+      const uint32_t pa = aA + (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+      a[0] = g2_lds128<4096>(pa); a[1] = g2_lds128<5120>(pa); a[2] = g2_lds128<6144>(pa); a[3] = g2_lds128<7168>(pa);
+    };
+    auto rdB = [&](auto half, int kt, v8s (&b)[2]) {           // column blocks 2 half, 2 half + 1
+      constexpr int J0 = decltype(half)::value * 2;
+      const uint32_t so = (uint32_t)(kt % G2_ST) * (G2_STAGE_SHORTS * 2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (B_KROWS) {
+          const v4s l = g2_ldstr<0>(aB[J0 + j] + so), h = g2_ldstr<2048>(aB[J0 + j] + so);
+          b[j] = (v8s){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+        } else {
+          b[j] = g2_lds128<0>(aB[J0 + j] + so);
+        }
+      }
+    };
+    auto quad = [&](auto ih, auto jh, const v8s (&a)[4], const v8s (&b)[2]) {
+      constexpr int I0 = decltype(ih)::value * 4, J0 = decltype(jh)::value * 2;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a[i]),
+                                                                         __builtin_bit_cast(v8bf, b[j]), acc[I0 + i][J0 + j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // The wave's 8 x 4 blocks as four quadrants (rows lo / hi x columns lo / hi) of 8 MFMAs; one register set per operand
+    // half (aL, aH, bL, bH) and the fragments of the NEXT k-tile are read into a set as soon as its last quadrant has
+    // issued, a quadrant or more ahead of their first use.  The order that makes this work alternates between k-tiles:
+    //   X: LL LH | HH HL     reads after LH: aL', after HH: bH', after HL: aH' bL'
+    //   Y: LH LL | HL HH     reads after LL: aL', after HL: bL', after HH: aH' bH'     ( | = vmcnt + barrier + DMA issue)
+    // LDS returns in order: the first quadrant of a k-tile waits for the two oldest groups, the second for everything.
+    typedef std::integral_constant<int, 0> LO;
+    typedef std::integral_constant<int, 1> HI;
+#define G2_WAIT_FIRST() do { if (B_KROWS) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); \
+                             else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); } while (0)
+#define G2_WAIT_ALL() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    v8s aL[4], aH[4], bL[2], bH[2];
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rdAL(0, aL); rdB(LO{}, 0, bL); rdAH(0, aH); rdB(HI{}, 0, bH);
+    auto mid = [&](int kt) {                       // stage kt+1 has landed everywhere; refill the stage of k-tile kt-1
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + G2_ST - 1 < nk) issue(kt + G2_ST - 1);
+    };
+    int kt = 0;
+    for (; kt + G2_ST < nk; kt += 2) {             // branch-free steady state: both k-tiles have a successor and a refill
+      G2_WAIT_FIRST(); quad(LO{}, LO{}, aL, bL);
+      G2_WAIT_ALL();   quad(LO{}, HI{}, aL, bH);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(kt + G2_ST - 1);
+      rdAL(kt + 1, aL);
+      quad(HI{}, HI{}, aH, bH);
+      rdB(HI{}, kt + 1, bH);
+      quad(HI{}, LO{}, aH, bL);
+      rdAH(kt + 1, aH); rdB(LO{}, kt + 1, bL);
+      G2_WAIT_FIRST(); quad(LO{}, HI{}, aL, bH);
+      G2_WAIT_ALL();   quad(LO{}, LO{}, aL, bL);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(kt + G2_ST);
+      rdAL(kt + 2, aL);
+      quad(HI{}, LO{}, aH, bL);
+      rdB(LO{}, kt + 2, bL);
+      quad(HI{}, HI{}, aH, bH);
+      rdAH(kt + 2, aH); rdB(HI{}, kt + 2, bH);
+    }
+    // (fragment reads are in flight here; the wait keeps any register shuffling between the two loops behind them)
+    G2_WAIT_ALL();
+    for (;; kt += 2) {
+      {                                            // X
+        const bool next = kt + 1 < nk;
+        G2_WAIT_FIRST(); quad(LO{}, LO{}, aL, bL);
+        G2_WAIT_ALL();   quad(LO{}, HI{}, aL, bH);
+        if (next) { mid(kt); rdAL(kt + 1, aL); }
+        quad(HI{}, HI{}, aH, bH);
+        if (next) rdB(HI{}, kt + 1, bH);
+        quad(HI{}, LO{}, aH, bL);
+        if (!next) break;
+        rdAH(kt + 1, aH); rdB(LO{}, kt + 1, bL);
+      }
+      {                                            // Y
+        const int k1 = kt + 1;
+        const bool next = k1 + 1 < nk;
+        G2_WAIT_FIRST(); quad(LO{}, HI{}, aL, bH);
+        G2_WAIT_ALL();   quad(LO{}, LO{}, aL, bL);
+        if (next) { mid(k1); rdAL(k1 + 1, aL); }
+        quad(HI{}, LO{}, aH, bL);
+        if (next) rdB(LO{}, k1 + 1, bL);
+        quad(HI{}, HI{}, aH, bH);
+        if (!next) break;
+        rdAH(k1 + 1, aH); rdB(HI{}, k1 + 1, bH);
+      }
+    }
+#undef G2_WAIT_FIRST
+#undef G2_WAIT_ALL
+  } else {
   auto mma = [&](const v8s (&a)[4], const v8s (&b)[2]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -352,7 +502,6 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a[i]),
                                                              __builtin_bit_cast(v8bf, b[j]), acc[i][j], 0, 0, 0);
   };
-  {
     // software-pipelined: the LDS reads of the next half k-tile are in flight under the MFMAs of the current one.
     // Stage kt+1 is awaited (own DMAs: vmcnt; everybody's: barrier) in the MIDDLE of k-tile kt, where the refill of
     // the stage consumed in k-tile kt-1 is issued too: two k-tiles of DMA in flight, one landed, one being read.
@@ -459,19 +608,19 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
     unsigned* stage = reinterpret_cast<unsigned*>(lds);            // [256 rows][128 dwords]
     const bool odd = fr & 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
+        for (int r = 0; r < NR; r += 2) {
           const float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
           const float send = odd ? v0 : v1;
           const float recv = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0xB1, 0xf, 0xf, true));
           __bf16 tl = (__bf16)(odd ? recv : v0), th = (__bf16)(odd ? v1 : recv);
           const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, tl) |
                               ((unsigned)__builtin_bit_cast(unsigned short, th) << 16);
-          const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh + (odd ? 1 : 0);
-          const int cd = (wn0 + j * 32 + (fr & ~1)) >> 1;          // dword column
+          const int row = wm0 + erow(i, r) + (odd ? 1 : 0);
+          const int cd = (wn0 + (ecol(j) & ~1)) >> 1;              // dword column
           stage[row * 128 + (cd ^ ((row & 7) << 2))] = pk;          // 16-byte chunks XOR-swizzled by row
         }
     __builtin_amdgcn_s_barrier();
@@ -522,15 +671,15 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
     for (int half = 0; half < 2; ++half) {
       if ((wave >> 2) == half) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int col = wn0 + j * 32 + fr;
+          for (int j = 0; j < NJ; ++j) {
+            const int col = wn0 + ecol(j);
             const int n = n0 + col;
             const float bv = (bias && n < N) ? bias[n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            for (int r = 0; r < NR; ++r) {
+              const int row = erow(i, r);
               float v = acc[i][j][r] + bv;
               if (relu) v = fmaxf(v, 0.f);
               stage[row * 256 + (col ^ (((row >> 2) & 1) << 5))] = v;      // the two lane halves (rows +4) on other banks
@@ -570,14 +719,14 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn0 + j * 32 + fr;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn0 + ecol(j);
       if (n >= N) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      for (int r = 0; r < NR; ++r) {
+        const int m = m0 + wm0 + erow(i, r);
         if (m >= M) continue;
         float v = acc[i][j][r];
         if (bias) v += bias[n];
@@ -595,6 +744,11 @@ gemm_bf16_256_kernel(const short* __restrict__ A, int lda, const short* __restri
     }
 }
 
+// MFMA shape of the ring kernel: MO_GEMM_MFMA=32 selects v_mfma_f32_32x32x16_bf16 (A/B switch, read once)
+static bool g2_mfma16() {
+  static const bool v = [] { const char* e = getenv("MO_GEMM_MFMA"); return !(e && atoi(e) == 32); }();
+  return v;
+}
 // a_kpad: number of readable columns of A (>= K rounded up to 32, zero beyond K)
 // fp32-result epilogue options (the head of the throughput mode): + bias[n], ReLU, and a ReLU-backward gate
 // (result zeroed where mask[m][n] <= 0; mask has D's shape and leading dimension)
@@ -610,12 +764,11 @@ extern "C" int mo_gemm_bf16_256_ex(const void* A, int lda, int a_kpad, const voi
   MO_CHECK_ARG(b_krows || (K % 32) == 0);          // XROWS B has no zero-padded operand to mask a K tail
   const int gm = mo_cdiv(M, G2_BM), gn = mo_cdiv(N, G2_BN);
   dim3 grid(8 * ((gm + 1) / 2) * ((gn + 3) / 4));
-  if (b_krows)
-    hipLaunchKernelGGL(gemm_bf16_256_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16, bias, relu, mask);
-  else
-    hipLaunchKernelGGL(gemm_bf16_256_kernel<false>, grid, dim3(512), 0, (hipStream_t)stream, (const short*)A, lda,
-                       (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16, bias, relu, mask);
+#define G2_LAUNCH(KR, MF) hipLaunchKernelGGL((gemm_bf16_256_kernel<KR, MF>), grid, dim3(512), 0, (hipStream_t)stream, \
+    (const short*)A, lda, (const short*)B, ldb, D, ldd, M, N, K, beta, (unsigned short*)D_bf16, bias, relu, mask)
+  if (g2_mfma16()) { if (b_krows) G2_LAUNCH(true, true); else G2_LAUNCH(false, true); }
+  else { if (b_krows) G2_LAUNCH(true, false); else G2_LAUNCH(false, false); }
+#undef G2_LAUNCH
   return mo_launch_status();
 }
 extern "C" int mo_gemm_bf16_256(const void* A, int lda, int a_kpad, const void* B, int ldb, int b_krows, float* D,

@@ -27,6 +27,7 @@ static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 =
 static int mo_opt_no_mfma_conv = 0;      // 1 = deep-level convs on the im2col tile engine / VALU direct kernel as before
 static int mo_opt_no_bf16_mfma = 0;      // 1 = MO_BF_MATH requests run on the fp32 kernels (A/B switch)
 static int mo_opt_ub_min_w = 64;          // narrowest image the bf16 matrix-pipe conv serves (32: also the 32 x 32 level)
+static int mo_opt_ub_ipw = 0;             // experiment: images per workgroup of the bf16 conv (0 = heuristic)
 static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
 extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!name) return MO_EINVAL;
@@ -34,6 +35,7 @@ extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!strcmp(name, "no_mfma_conv")) { mo_opt_no_mfma_conv = value; return MO_OK; }
   if (!strcmp(name, "no_bf16_mfma")) { mo_opt_no_bf16_mfma = value; return MO_OK; }
   if (!strcmp(name, "ub_min_w")) { mo_opt_ub_min_w = value; return MO_OK; }
+  if (!strcmp(name, "ub_ipw")) { mo_opt_ub_ipw = value; return MO_OK; }
   if (!strcmp(name, "ux_min_co")) { mo_opt_ux_min_co = value; return MO_OK; }
   return MO_EINVAL;
 }
@@ -234,6 +236,7 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     A.flip = (dtypes & MO_W_FLIP) != 0; A.n_img = (int)n_img;
     const long bands = H / UB_TH;                         // a workgroup = one band of 16 rows x a range of images
     long ipw = (bands * n_img) / 1024;                    // (weights / staging pattern are set up once per workgroup)
+    if (mo_opt_ub_ipw > 0) ipw = mo_opt_ub_ipw;
     if (ipw < 1) ipw = 1;
     while ((n_img + ipw - 1) / ipw >= 65536) ++ipw;
     A.img_per_wg = (int)ipw;
