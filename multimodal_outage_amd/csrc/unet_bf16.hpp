@@ -49,14 +49,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ub_rsrc(const void* p, long by
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
 }
 
-template <int CP, int NB, int RB, bool TWO, int TW = UB_TW>   // padded input channels (4, 8, 16, 32), blocks of 16 output
+// Thin outputs (Co <= 4 / <= 8: every 256^2 and 128^2 layer of the UNet) with D[pixel][co] leave 12 / 8 of the MFMA's 16
+// columns -- and of the epilogue's lanes -- idle.  DX = 4 / 2 packs DX neighbouring pixels of a row into the 16 rows of
+// the product instead:  D[m = (co, dx)][n = pixel group] += A[m][k] * B[k][n],  k = (ky, column x_n - 1 + c, ci) over the
+// DX + 2 columns the group's taps touch,  A[(co, dx)][(ky, c, ci)] = W[co][ci][ky][c - dx] (zero outside the 3 taps),
+// B = the channels-last tile as it lies in LDS (the (DX + 2) * CP values of a group and row are contiguous).  One MFMA
+// tile then covers 16 * DX pixels of a row for all output channels: 3 instead of 8 MFMAs (and LDS fragment reads) per 64
+// pixels at Ci = Co = 4, a lane ends up with DX consecutive pixels of a channel, and every lane has an output.
+template <int CP, int NB, int RB, bool TWO, int TW = UB_TW, int DX = 1>   // padded input channels (4, 8, 16, 32), blocks of 16 output
                                                // channels, rows per band, TWO: two views of CP/2 channels each (the skip /
-                                               // up concat), TW: tile width (64; 32 for 32-pixel-wide images)
+                                               // up concat), TW: tile width (64; 32 for 32-pixel-wide images), DX: pixels
+                                               // per MFMA row group (1; 4 / 2 for Co <= 4 / 8, NB = 1, TW = 64, CP <= 16)
 __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
+  static_assert(DX == 1 || (NB == 1 && TW == 64 && CP <= 16 && (DX == 2 || DX == 4)), "packed variant: thin outputs only");
   constexpr int TH = UB_TH, LDT = TW + 8;                 // col = x - x0 + 4: whole quads x0-4 .. x0+TW+3 are staged
   constexpr int CPC = CP >= 8 ? CP / 8 : 1;               // 16-byte chunks per pixel
-  constexpr int NCH = CP == 4 ? 6 : 9 * CPC;              // k chunks of 8
-  constexpr int NM = (NCH + 3) / 4;                       // MFMAs per 16-pixel block and output block
+  constexpr int CPK = (DX + 2) * CP / 8;                  // packed variant: k chunks of 8 per kernel row
+  constexpr int NCH = DX > 1 ? 3 * CPK : (CP == 4 ? 6 : 9 * CPC);   // k chunks of 8
+  constexpr int NM = (NCH + 3) / 4;                       // MFMAs per 16-pixel block (per 16 * DX pixels) and output block
+  constexpr int NTB = TW / (16 * DX);                     // MFMA tiles per tile row
   constexpr int NR = RB + 2, QH = TW / 4 + 2;
   constexpr int CQS = TWO ? CP / 8 : CP / 4;              // channel quads per source
   constexpr int NTASK = CQS * NR * QH;                    // staging tasks per source and band (4 pixels x 4 channels each)
@@ -90,10 +101,16 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
         for (int j = 0; j < 8; ++j) {
           int ci, tap;
           bool ok = c < NCH && co < a.Co;
-          if (CP == 4) { const int kx = 2 * (c & 1) + (j >> 2); ci = j & 3; tap = (c >> 1) * 3 + kx; ok = ok && kx < 3; }
+          if (DX > 1) {                                     // row m = lp = (co, dx); k = (ky, column, ci)
+            const int e = (c % CPK) * 8 + j, col = e / CP, kx = col - (lp % DX);
+            ci = e % CP; tap = (c / CPK) * 3 + kx;
+            ok = c < NCH && (lp / DX) < a.Co && kx >= 0 && kx < 3;
+            if (!ok) tap = 0;
+          }
+          else if (CP == 4) { const int kx = 2 * (c & 1) + (j >> 2); ci = j & 3; tap = (c >> 1) * 3 + kx; ok = ok && kx < 3; }
           else { tap = c / CPC; ci = (c % CPC) * 8 + j; }
           ok = ok && ci < Ci;
-          const int cic = min(ci, Ci - 1), coc = min(co, a.Co - 1), tc = min(tap, 8);
+          const int cic = min(ci, Ci - 1), coc = min(DX > 1 ? lp / DX : co, a.Co - 1), tc = min(tap, 8);
           const float w = a.W[A.flip ? ((long)cic * a.Co + coc) * 9 + 8 - tc : ((long)coc * Ci + cic) * 9 + tc];
           wr[m][nb][j] = ok ? w : 0.f;
         }
@@ -112,7 +129,8 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     int c = 4 * m + lg;
     if (c >= NCH) c = 0;                                  // (its weights are zero; any finite data will do)
     int o;
-    if (CP == 4) o = (((c >> 1) * LDT + lp + 2 * (c & 1) + 3) * CP) * 2;
+    if (DX > 1) o = (((c / CPK) * LDT + DX * lp + 3) * CP + (c % CPK) * 8) * 2;   // group lp's columns x_n - 1 .. of row ky
+    else if (CP == 4) o = (((c >> 1) * LDT + lp + 2 * (c & 1) + 3) * CP) * 2;
     else { const int tap = c / CPC, ky = tap / 3, kx = tap - 3 * ky; o = ((ky * LDT + lp + kx + 3) * CP + (c % CPC) * 8) * 2; }
     abase[m] = o + wave * WR * LDT * CP * 2;
   }
@@ -130,10 +148,13 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
     tdst[t] = (idx < NTASK) ? (r * LDT + 4 * q) * CP + cq * 4 : -1;
   }
   // output: lane (co = lp + 16 nb, pixels 4 lg .. 4 lg + 3 of a block)
-  unsigned vout[NB];
+  constexpr int NVO = DX == 2 ? 2 : NB;                   // (packed: lane = channel lg and 4 pixels, or channels 2 lg, 2 lg + 1 and 2 pixels)
+  unsigned vout[NVO];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-    vout[nb] = (nb * 16 + lp < a.Co) ? (unsigned)((((nb * 16 + lp) * a.H + y0 + wave * WR) * a.Wd + 4 * lg) * eso) : UB_OOB;
+  for (int nb = 0; nb < NVO; ++nb) {
+    const int co = DX == 4 ? lg : (DX == 2 ? 2 * lg + nb : nb * 16 + lp);
+    vout[nb] = (co < a.Co) ? (unsigned)(((co * a.H + y0 + wave * WR) * a.Wd + (DX > 1 ? DX * lp : 4 * lg)) * eso) : UB_OOB;
+  }
 
   // ---- the workgroup's stages: (image, tile of the row band, band of RB rows) in order.  Software pipeline: the global loads of stage k+1 are
   // issued in front of the matrix phase of stage k and wait in registers, so their latency is covered by it:
@@ -218,14 +239,68 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
       }
     }
   };
-  float s1[NB], s2[NB];
+  float s1[NVO], s2[NVO];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+  for (int nb = 0; nb < NVO; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
   auto matrix_phase = [&](auto bfoc, const long img, const int tx, const int b) {
     constexpr bool BFO = decltype(bfoc)::value;
     constexpr int eo = BFO ? 2 : 4;
     const __amdgpu_buffer_rsrc_t ro = ub_rsrc(reinterpret_cast<char*>(a.out) + img * a.os * eo, (long)a.Co * HW * eo);
     const char* lds = reinterpret_cast<const char*>(tile);
+    if constexpr (DX > 1) {
+#pragma unroll 1
+      for (int rr = 0; rr < WR; ++rr) {
+        unsigned vo[NVO];
+#pragma unroll
+        for (int nb = 0; nb < NVO; ++nb) vo[nb] = vout[nb] + (unsigned)(((b * RB + rr) * a.Wd + tx * TW) * eo);
+        ub_f4 acc[NTB];
+#pragma unroll
+        for (int tb = 0; tb < NTB; ++tb) acc[tb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+          for (int tb = 0; tb < NTB; ++tb) {
+            const char* ap = lds + (abase[m] + rr * (LDT * CP * 2)) + tb * 16 * DX * CP * 2;
+            ub_bf8 pf;
+            if (CP == 4) {                                  // 8-byte aligned only
+              const uint2 lo = *reinterpret_cast<const uint2*>(ap);
+              const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
+              pf = __builtin_bit_cast(ub_bf8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            } else {
+              pf = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const uint4*>(ap));
+            }
+            acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m][0], pf, acc[tb], 0, 0, 0);
+          }
+        // D[m = 4 lg + r][n = lp]: DX = 4: channel lg, pixels 4 lp + r;  DX = 2: channels 2 lg + (r >> 1), pixels 2 lp + (r & 1)
+#pragma unroll
+        for (int tb = 0; tb < NTB; ++tb) {
+          const float c0 = acc[tb][0], c1 = acc[tb][1], c2 = acc[tb][2], c3 = acc[tb][3];
+          if (DX == 4) {
+            if (BFO) {
+              const ub_u2 pk = {ub_pack2(c0, c1), ub_pack2(c2, c3)};
+              __builtin_amdgcn_raw_buffer_store_b64(pk, ro, (int)vo[0], 0, 0);
+            } else {
+              const ub_u4 pk = {__float_as_uint(c0), __float_as_uint(c1), __float_as_uint(c2), __float_as_uint(c3)};
+              __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)vo[0], 0, 0);
+            }
+            s1[0] += (c0 + c1) + (c2 + c3);
+            s2[0] += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
+          } else {
+            if (BFO) {
+              __builtin_amdgcn_raw_buffer_store_b32(ub_pack2(c0, c1), ro, (int)(vo[0] + tb * 64), 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(ub_pack2(c2, c3), ro, (int)(vo[1] + tb * 64), 0, 0);
+            } else {
+              const ub_u2 p0 = {__float_as_uint(c0), __float_as_uint(c1)}, p1 = {__float_as_uint(c2), __float_as_uint(c3)};
+              __builtin_amdgcn_raw_buffer_store_b64(p0, ro, (int)(vo[0] + tb * 128), 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(p1, ro, (int)(vo[1] + tb * 128), 0, 0);
+            }
+            s1[0] += c0 + c1; s2[0] += c0 * c0 + c1 * c1;
+            s1[1] += c2 + c3; s2[1] += c2 * c2 + c3 * c3;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll 1
     for (int rr = 0; rr < WR; ++rr) {
       unsigned vo[NB];
@@ -303,11 +378,18 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
                                                           // per image and 16-row band: the finalize kernel walks 4x fewer
                                                           // rows than with one per tile)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NVO; ++nb) {
           float t1 = s1[nb], t2 = s2[nb];
-          t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
-          t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
-          if (lg == 0) { red[wave][2 * (nb * 16 + lp)] = t1; red[wave][2 * (nb * 16 + lp) + 1] = t2; }
+          if (DX > 1) {                                     // a channel's sums lie in the 16 lanes of a group
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+            const int co = DX == 4 ? lg : 2 * lg + nb;
+            if (lp == 0) { red[wave][2 * co] = t1; red[wave][2 * co + 1] = t2; }
+          } else {
+            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+            if (lg == 0) { red[wave][2 * (nb * 16 + lp)] = t1; red[wave][2 * (nb * 16 + lp) + 1] = t2; }
+          }
         }
         __syncthreads();
         if (tid < 32 * NB && (tid >> 1) < a.Co) {
@@ -316,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
         }
       }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+      for (int nb = 0; nb < NVO; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
     }
   };
   if (nstage > 0) { load_affine(img0); issue_loads(0, UbInt<0>{}); }

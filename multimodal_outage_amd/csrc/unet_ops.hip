@@ -27,6 +27,7 @@ static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 =
 static int mo_opt_no_mfma_conv = 0;      // 1 = deep-level convs on the im2col tile engine / VALU direct kernel as before
 static int mo_opt_no_bf16_mfma = 0;      // 1 = MO_BF_MATH requests run on the fp32 kernels (A/B switch)
 static int mo_opt_ub_min_w = 64;          // narrowest image the bf16 matrix-pipe conv serves (32: also the 32 x 32 level)
+static int mo_opt_ub_no_pack = 0;         // A/B switch: 1 = thin outputs on the unpacked D[pixel][co] kernel
 static int mo_opt_ub_ipw = 0;             // experiment: images per workgroup of the bf16 conv (0 = heuristic)
 static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
 extern "C" int mo_unet_set_option(const char* name, int value) {
@@ -35,6 +36,7 @@ extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!strcmp(name, "no_mfma_conv")) { mo_opt_no_mfma_conv = value; return MO_OK; }
   if (!strcmp(name, "no_bf16_mfma")) { mo_opt_no_bf16_mfma = value; return MO_OK; }
   if (!strcmp(name, "ub_min_w")) { mo_opt_ub_min_w = value; return MO_OK; }
+  if (!strcmp(name, "ub_no_pack")) { mo_opt_ub_no_pack = value; return MO_OK; }
   if (!strcmp(name, "ub_ipw")) { mo_opt_ub_ipw = value; return MO_OK; }
   if (!strcmp(name, "ux_min_co")) { mo_opt_ux_min_co = value; return MO_OK; }
   return MO_EINVAL;
@@ -204,6 +206,14 @@ static void ub_launch(const UbConvArgs& A, int Co, bool two, dim3 grid, hipStrea
   if (Co <= 16) hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 1, RB, false, TW>), grid, dim3(256), 0, st, A);
   else hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 2, RB, false, TW>), grid, dim3(256), 0, st, A);
 }
+// thin outputs at 64-pixel tiles: DX pixels of a row per MFMA row group (unet_bf16.hpp)
+template <int CP, int RB, int DX>
+static void ub_launch_packed(const UbConvArgs& A, bool two, dim3 grid, hipStream_t st) {
+  if constexpr (CP >= 8) {
+    if (two) { hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 1, RB, true, UB_TW, DX>), grid, dim3(256), 0, st, A); return; }
+  }
+  hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 1, RB, false, UB_TW, DX>), grid, dim3(256), 0, st, A);
+}
 extern "C" int mo_conv3x3_stats_tiles(int Co, long n_img, int H, int Wd) {
   const int tw = ux_tw(Co, n_img, H, Wd);
   if (tw && ux_preferred(Co, H, Wd)) return (Wd / tw) * (H / (256 / tw));
@@ -235,14 +245,25 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     a.off0 = reinterpret_cast<const long*>(in0_off);
     A.flip = (dtypes & MO_W_FLIP) != 0; A.n_img = (int)n_img;
     const long bands = H / UB_TH;                         // a workgroup = one band of 16 rows x a range of images
-    long ipw = (bands * n_img) / 1024;                    // (weights / staging pattern are set up once per workgroup)
+    long ipw = (bands * n_img) / 2048;                    // (weights / staging pattern are set up once per workgroup;
+                                                          //  2144 workgroups of one image beat 1072 of two by 8 % at 256^2)
     if (mo_opt_ub_ipw > 0) ipw = mo_opt_ub_ipw;
     if (ipw < 1) ipw = 1;
     while ((n_img + ipw - 1) / ipw >= 65536) ++ipw;
     A.img_per_wg = (int)ipw;
     dim3 grid((unsigned)bands, (unsigned)((n_img + ipw - 1) / ipw));
     hipStream_t st = ST(stream);
-    if (ub_tw(Wd) == 64) {
+    // (13 -> 4 at 256^2, the one layer with Ci > 8 and Co <= 4: 9 weight fragments per lane, 222 us packed vs 209 us)
+    if (ub_tw(Wd) == 64 && Co <= 8 && Ci <= (Co <= 4 ? 8 : 16) && !mo_opt_ub_no_pack) {
+      if (Co <= 4) {
+        if (Ci <= 4) ub_launch_packed<4, 16, 4>(A, false, grid, st);
+        else ub_launch_packed<8, 16, 4>(A, C1 > 0, grid, st);
+      } else {
+        if (Ci <= 4) ub_launch_packed<4, 16, 2>(A, false, grid, st);
+        else if (Ci <= 8) ub_launch_packed<8, 16, 2>(A, C1 > 0, grid, st);
+        else ub_launch_packed<16, 8, 2>(A, C1 > 0, grid, st);
+      }
+    } else if (ub_tw(Wd) == 64) {
       if (Ci <= 4) ub_launch<4, 16>(A, Co, false, grid, st);
       else if (Ci <= 8) ub_launch<8, 16>(A, Co, C1 > 0, grid, st);
       else if (Ci <= 16) ub_launch<16, 8>(A, Co, C1 > 0, grid, st);
