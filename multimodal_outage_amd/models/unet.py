@@ -268,8 +268,10 @@ class Modified_UNET(nn.Module):
             st_e['st_gnn_in_place'] = self.st_gnn._mo_grad_out is not None
         else:
             z = torch.stack([self.st_gnn(o[b]) for b in range(B)]).reshape(n, feature_vector_size)
+        # (defer_join: the decoder's weight-gradient lane is joined at the end of the contraction's backward, which
+        #  follows it in this graph -- unet_engine._Lane.defer)
         st_d = dict(state, names=dec_names, skip_meta=st_e['skip_meta'],
-                    fc_dropout=self.decoder.dropout1.p)
+                    fc_dropout=self.decoder.dropout1.p, defer_join=state['grad_out'] is not None)
         if target is not None:
             Cout = self.expansion.outc.conv.weight.shape[0]
             assert tuple(target.shape) == (B, NC, H, Cout, S, S), 'target must have the shape of the prediction'

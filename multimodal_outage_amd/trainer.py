@@ -24,6 +24,12 @@ from . import _lib as L
 _ALIGN = 64   # floats (256 B): every parameter starts on a 16-byte boundary for vector loads
 
 
+def _join_deferred_lanes():
+    from . import unet_engine
+    if unet_engine._Lane._deferred:
+        unet_engine.join_deferred()
+
+
 class FlatTrainer:
     def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap=True,
                  force_collectives=False, collective='allreduce', comm='torch', eager_adam=False):
@@ -202,6 +208,7 @@ class FlatTrainer:
 
     def allreduce(self, async_op=False):
         """Reduce every range not announced through mark_ready, then wait for the asynchronous buckets."""
+        _join_deferred_lanes()
         if not self.collectives:
             return None
         done = sorted(self._done)
@@ -251,6 +258,7 @@ class FlatTrainer:
     def step(self):
         """Adam on the flat buffer (what adam_now has not updated already in this step); gradients are averaged over
         ranks (grad_scale = 1/world)."""
+        _join_deferred_lanes()
         self.step_count += 1
         pos = 0
         for lo, hi in sorted(self._stepped) + [(self.total, self.total)]:

@@ -26,13 +26,14 @@ class _Lane:
     per call, 45 calls per step), and every tensor they touch -- operands allocated on the main stream, workspaces -- is
     simply kept alive until join(): after the main stream has waited for the lane, the allocator may recycle them."""
     _streams = {}
+    _deferred = {}
 
     def __init__(self, dev, enabled=True):
         self.main = torch.cuda.current_stream()
         self.side = None
         self.held = []
         if enabled and WGRAD_LANE:
-            key = (torch.device(dev).index, 'unet_wgrad')
+            key = self.key = (torch.device(dev).index, 'unet_wgrad')
             if key not in _Lane._streams:
                 _Lane._streams[key] = torch.cuda.Stream(device=dev)
             self.side = _Lane._streams[key]
@@ -57,6 +58,26 @@ class _Lane:
         if self.side is not None:
             self.main.wait_stream(self.side)
             self.held.clear()
+            _Lane._deferred.pop(self.key, None)
+
+    def defer(self):
+        """Instead of join(): leave the lane's work running beside whatever the main stream does next and hand the tensors
+        it uses to the NEXT join() on this side stream.  Only for a backward whose lane results (in-place parameter
+        gradients) have no consumer on the main stream before that join -- the decoder's backward inside Modified_UNET,
+        which the Graph WaveNet's and the contraction's backward follow (the main stream idled ~0.3 ms of a 7 ms step
+        waiting for the decoder's last weight gradients and their Adam update)."""
+        if self.side is not None:
+            _Lane._deferred.setdefault(self.key, []).extend(self.held)
+            self.held = []
+
+
+def join_deferred():
+    """The current stream waits for every weight-gradient lane whose join was deferred (_Lane.defer) and has not happened
+    since -- called by the trainer in front of the collectives / the optimizer step, for graphs in which the backward
+    that would have joined the lane did not run (a frozen contraction)."""
+    for key in list(_Lane._deferred):
+        torch.cuda.current_stream().wait_stream(_Lane._streams[key])
+        _Lane._deferred.pop(key, None)
 
 
 ENC_CH = ((4, 8), (8, 16), (16, 32), (32, 64))      # down1..4 (unet.py:100-103)
@@ -562,6 +583,10 @@ class UnetDecodeFn(torch.autograd.Function):
         dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads, lane=lane)
         if state.get('adam_now') is not None and state.get('grad_out'):
             lane.run(lambda ls: state['adam_now'](('decoder.', 'expansion.'), ls))      # (eager Adam, see UnetEncodeFn.backward)
-        lane.join()
+        gout = state.get('grad_out') or {}
+        if state.get('defer_join') and all(gout.get(k) is not None for k in state['names']):
+            lane.defer()                         # (every gradient of this pass went into the trainer's buffers in place)
+        else:
+            lane.join()
         ctx.fc_sv = ctx.ups = ctx.vlast = ctx.loss_da = ctx.loss_ws = None      # (release the activations, see UnetEncodeFn)
         return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(state['names'])

@@ -41,7 +41,9 @@ def timeit(fn, reps=a.reps):
 
 # (C0, bf0, C1, Co, S): first view (bf16-stored unless the network input), second view (fp32 upsampled map), size
 LAYERS = [(13, 0, 0, 4, 256), (4, 1, 0, 4, 256), (4, 1, 4, 4, 256), (4, 1, 0, 8, 128), (8, 1, 0, 8, 128), (8, 1, 8, 8, 128),
-          (8, 1, 0, 16, 64), (16, 1, 0, 16, 64), (16, 1, 16, 16, 64)]
+          (8, 1, 0, 16, 64), (16, 1, 0, 16, 64), (16, 1, 16, 16, 64),
+          # deep levels (exact-fp32 matrix pipe in both modes)
+          (16, 1, 0, 32, 32), (32, 1, 0, 32, 32), (32, 1, 32, 32, 32), (32, 1, 0, 64, 16), (64, 1, 0, 64, 16)]
 print(f'{"layer":26s} {"op":6s} {"fp32 us":>9s} {"bf16-mfma us":>13s} {"MB":>8s} {"TB/s (mfma)":>12s}')
 if a.layers:
     LAYERS = [LAYERS[int(i)] for i in a.layers.split(',')]
