@@ -24,6 +24,7 @@ struct UfcArgs {
   float* slab;                           // [gridDim.y][P][C]
   int P, R, C;                           // rows, reduction length, output columns
   int chunks_per_split;                  // chunks of UFC_KC per workgroup
+  int groups_in_grid;                    // 1: row group = blockIdx.z;  0: every workgroup walks all row groups
 };
 
 __global__ void ufc_split_kernel(const float* __restrict__ x, long n, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
@@ -74,8 +75,11 @@ __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
   // More rows than 16 * MB (several windows per step): row groups of 16 * MB, one after the other INSIDE the workgroup -- its
   // weight panel (64 columns x its share of the reduction, ~256 KB) is then re-read from L2 / the Infinity Cache instead of
   // the whole 268 MB matrix being streamed from HBM once per group by separate launches.
+  // (WMODE 1 re-reads its panel by 4-byte column accesses: there the groups go into the grid instead -- blockIdx.z --
+  //  so that the groups of a panel run side by side: 4 windows 995 -> see DESIGN.md 5)
   const int ngroups = (a.P + ROWS - 1) / ROWS;
-  for (int rg = 0; rg < ngroups; ++rg) {
+  const int rg_first = a.groups_in_grid ? (int)blockIdx.z : 0, rg_last = a.groups_in_grid ? (int)blockIdx.z + 1 : ngroups;
+  for (int rg = rg_first; rg < rg_last; ++rg) {
   const int prow = rg * ROWS;
   ub_f4 acc[MB];
 #pragma unroll

@@ -27,6 +27,7 @@ static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 =
 static int mo_opt_no_mfma_conv = 0;      // 1 = deep-level convs on the im2col tile engine / VALU direct kernel as before
 static int mo_opt_no_bf16_mfma = 0;      // 1 = MO_BF_MATH requests run on the fp32 kernels (A/B switch)
 static int mo_opt_ub_min_w = 64;          // narrowest image the bf16 matrix-pipe conv serves (32: also the 32 x 32 level)
+static int mo_opt_fc_groups_grid = 0;     // FC row groups of 144: 0 = in the grid for the data gradient only, 1 = always, 2 = never
 static int mo_opt_ub_no_pack = 0;         // A/B switch: 1 = thin outputs on the unpacked D[pixel][co] kernel
 static int mo_opt_ub_ipw = 0;             // experiment: images per workgroup of the bf16 conv (0 = heuristic)
 static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
@@ -36,6 +37,7 @@ extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!strcmp(name, "no_mfma_conv")) { mo_opt_no_mfma_conv = value; return MO_OK; }
   if (!strcmp(name, "no_bf16_mfma")) { mo_opt_no_bf16_mfma = value; return MO_OK; }
   if (!strcmp(name, "ub_min_w")) { mo_opt_ub_min_w = value; return MO_OK; }
+  if (!strcmp(name, "fc_groups_grid")) { mo_opt_fc_groups_grid = value; return MO_OK; }
   if (!strcmp(name, "ub_no_pack")) { mo_opt_ub_no_pack = value; return MO_OK; }
   if (!strcmp(name, "ub_ipw")) { mo_opt_ub_ipw = value; return MO_OK; }
   if (!strcmp(name, "ux_min_co")) { mo_opt_ux_min_co = value; return MO_OK; }
@@ -925,7 +927,9 @@ static int ufc_run(const float* a, long P, int R, const float* W, int C, const f
     (void)hipFuncSetAttribute((const void*)ufc_kernel<WMODE, UFC_MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB>), dim3(mo_cdiv(C, 64), ks), dim3(256), lds, st, A);
+  const int ngroups = (int)mo_cdiv(P, (long)UFC_MB * 16);
+  A.groups_in_grid = ngroups > 1 && (mo_opt_fc_groups_grid == 1 || (mo_opt_fc_groups_grid == 0 && WMODE == 1));
+  hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB>), dim3(mo_cdiv(C, 64), ks, A.groups_in_grid ? ngroups : 1), dim3(256), lds, st, A);
   const long no = P * (long)C;
   hipLaunchKernelGGL(ufc_reduce_kernel, dim3(mo_cdiv(no, 256)), dim3(256), 0, st, slab, no, ks, bias, C, relu, out, no);
   return mo_launch_status();

@@ -895,14 +895,17 @@ class GwnetSmallFunction(torch.autograd.Function):
                L.ptr(ws_for(cfg.Cs, 32 * Lc, rows)), st)
         gWs = [gbuf(f'skip_convs.{i}.weight', p[f'skip_convs.{i}.weight']) for i in range(Lc)]
         L.call('mo_skip_wsplit', L.ptr(dWcat), cfg.Cs, Lc, L.ptr_array(gWs), st)
+        sbs = []
         for i in range(Lc):
             grads[f'skip_convs.{i}.weight'] = gWs[i]
             sb = gout.get(f'skip_convs.{i}.bias')
             if sb is not None:
-                sb.copy_(dbs)
+                sbs.append(sb)
                 grads[f'skip_convs.{i}.bias'] = sb
             else:
                 grads[f'skip_convs.{i}.bias'] = dbs
+        if sbs:
+            torch._foreach_copy_(sbs, [dbs] * len(sbs))      # (one multi-tensor launch)
         # the layer stack
         dsts = []
         for i in range(Lc):

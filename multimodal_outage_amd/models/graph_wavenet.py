@@ -312,8 +312,8 @@ class gwnet(nn.Module):
         params = [cache.named[k] for k in names]
         bn_bufs = [cache.bn[f'bn.{i}'][:2] for i in range(len(self.bn))]
         if self.training:
-            for m in self.bn:
-                m.num_batches_tracked += B                      # one BatchNorm2d call per layer and forward call
+            # one BatchNorm2d call per layer and forward call (one multi-tensor launch instead of one per layer)
+            torch._foreach_add_([m.num_batches_tracked for m in self.bn], B)
         x = inputs.float().contiguous().view(B, self.in_dim, self.num_nodes, self.horizon)    # :189, per call
         y = GwnetSmallFunction.apply(cfg, self._small_dense(inputs.device), bn_bufs, self.training, x, *params)
         return y.view(B, self.num_nodes, self.horizon, self.out_dim)                           # :255, per call

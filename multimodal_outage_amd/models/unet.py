@@ -248,6 +248,7 @@ class Modified_UNET(nn.Module):
         state = dict(gsize=H, training=self.training, bufs=bufs,
                      fc_dropout=self.encoder.dropout1.p, grad_out=getattr(self, '_mo_grad_out', None),
                      act_dtype=getattr(self, 'act_dtype', 'f32'), adam_now=getattr(self, '_mo_adam_now', None))
+        state['skip_side'] = {} if self.training else None     # (skip-map gradients: decoder -> contraction, unet_engine)
         st_e = dict(state, names=enc_names)
         x_off = self._image_offsets(input, n) if input.dtype == torch.float32 else False
         if x_off is None or x_off is False or S < 32 or S % 4 or Cin > 32:

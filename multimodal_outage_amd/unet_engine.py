@@ -412,6 +412,12 @@ class UnetEncodeFn(torch.autograd.Function):
         # round 1's UNet bench leg.  They go through save_for_backward and are put back in backward.
         outs = (feat,) + tuple(v.t for v in views[:4])
         ctx.save_for_backward(*outs)
+        if state.get('skip_side') is not None:
+            # Modified_UNET: the skip maps' gradients come back through state['skip_side'] (set by UnetDecodeFn.backward,
+            # which always runs first: feat -> st_gnn -> z -> decoder), not through autograd -- which would cast the fp32
+            # channel slices of the decoder's concat gradient to the maps' bf16 (four strided copies, 250 MB per window)
+            ctx.mark_non_differentiable(*outs[1:])
+            ctx.set_materialize_grads(False)
         fc_sv['h2'] = None
         for k in range(4):
             saved[k]['y2'] = None
@@ -440,6 +446,9 @@ class UnetEncodeFn(torch.autograd.Function):
         dp = double_conv_bwd(p, saved[4], n, gs, grads, dev, da=dx5a.view(n, v5['Co'], v5['H'], v5['W']), dp=None,
                              dx_bf=bool(saved[4]['views'][0].bf), lane=lane)
         dfm = [dfm1, dfm2, dfm3, dfm4]
+        side = state.get('skip_side')
+        if side is not None:
+            dfm = side.pop('dfm', dfm)
         for k in (3, 2, 1, 0):
             need = (k > 0) or ctx.x_needs_grad
             # the gradient w.r.t. a level's pooled input is the dp of the level above: stored as that input is
@@ -589,4 +598,7 @@ class UnetDecodeFn(torch.autograd.Function):
         else:
             lane.join()
         ctx.fc_sv = ctx.ups = ctx.vlast = ctx.loss_da = ctx.loss_ws = None      # (release the activations, see UnetEncodeFn)
+        if state.get('skip_side') is not None:
+            state['skip_side']['dfm'] = dfm      # (picked up by UnetEncodeFn.backward)
+            return (None, dz, None, None, None, None) + grads.result(state['names'])
         return (None, dz, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(state['names'])
