@@ -33,6 +33,17 @@ typedef __bf16 ub_bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned ub_pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((ub_f2){lo, hi}, ub_bf2));
 }
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in dispatch order.  A (band, image range) grid
+// dispatched as it stands puts vertically neighbouring bands -- which share two halo rows of every tile -- on different
+// XCDs, so every halo row comes from HBM / the Infinity Cache twice.  Renumbered, XCD x works through a CONTIGUOUS range of
+// (image range, band) pairs, band fastest: the bands of an image range run side by side on one L2.  (Bijective for any
+// grid size; placement only matters for speed.)
+__device__ __forceinline__ void ub_xcd_remap(int& band, int& chunk) {
+  const unsigned nwg = gridDim.x * gridDim.y, l = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned xcd = l & 7, slot = l >> 3, q = nwg >> 3, r = nwg & 7;
+  const unsigned w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  band = (int)(w % gridDim.x); chunk = (int)(w / gridDim.x);
+}
 template <bool B> struct UbBool { static constexpr bool value = B; };
 template <int N> struct UbInt { static constexpr int value = N; };
 
@@ -83,7 +94,9 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   // cache lines a tile shares with its neighbour (the halo quad of a 128-byte bf16 row segment is a whole extra line on
   // either side) are then re-read by the same CU a moment later instead of by another XCD from HBM
   const int tiles_x = a.Wd / TW;
-  const int y0 = blockIdx.x * TH;
+  int bandx, chunky;
+  ub_xcd_remap(bandx, chunky);
+  const int y0 = bandx * TH;
   const int Ci = a.C0 + a.C1;
   const int es0 = a.bf0 ? 2 : 4, es1 = a.bf1 ? 2 : 4, eso = a.bfo ? 2 : 4;
   const int HW = a.H * a.Wd;
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   // issued in front of the matrix phase of stage k and wait in registers, so their latency is covered by it:
   //   barrier | convert + write LDS (stage k) | barrier | issue loads (k+1) | matrix phase (k) | ...
   constexpr int NBI = TH / RB;                            // bands per image
-  const long img0 = (long)blockIdx.y * A.img_per_wg;
+  const long img0 = (long)chunky * A.img_per_wg;
   const long img1 = min(img0 + (long)A.img_per_wg, (long)A.n_img);
   const int SPI = NBI * tiles_x;                          // stages per image
   const int nstage = (int)(img1 - img0) * SPI;
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
         }
         __syncthreads();
         if (tid < 32 * NB && (tid >> 1) < a.Co) {
-          a.stats[((img * (long)gridDim.x + (long)blockIdx.x) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
+          a.stats[((img * (long)gridDim.x + (long)bandx) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
               (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         }
       }
@@ -445,7 +458,9 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
   __shared__ float aff[2][CI];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
   const int tiles_x = a.Wd / TW;                         // (a workgroup walks the tiles of its row band left to right,
-  const int y0 = blockIdx.x * TH;                         //  as ub_conv3x3_kernel does)
+  int bandx, chunky;
+  ub_xcd_remap(bandx, chunky);                            // (bands of an image range on one XCD, see above)
+  const int y0 = bandx * TH;                              //  as ub_conv3x3_kernel does)
   const int Ci = a.C0 + a.C1;
   const int HW = a.H * a.Wd;
 
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[j][kx][nb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
 
-  const long img0 = (long)blockIdx.y * a.img_per_wg;
+  const long img0 = (long)chunky * a.img_per_wg;
   const long img1 = min(img0 + (long)a.img_per_wg, a.n_img);
   const int SPI = NBI * tiles_x;                          // stages per image
   const int nstage = (int)(img1 - img0) * SPI;
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void ub_wgrad3x3_kernel(UdWgradArgs a) {
     }
   }
   __syncthreads();
-  const long z = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  const long z = (long)chunky * gridDim.x + bandx;
   float* row = a.slab + z * ((long)a.Co * Ci * 9);
   for (int e = tid; e < NJ * 3 * NB * 256; e += 256) {
     const int blk = e >> 8, l = (e >> 2) & 63, r = e & 3;

@@ -99,6 +99,7 @@ class FlatTrainer:
         # Opt-in: parameters change DURING backward, so every backward pass must be followed by step().
         self.eager_adam = bool(eager_adam) and not self.collectives
         self._stepped = []       # [lo, hi) ranges already updated in this step
+        self._overwritten = []   # [lo, hi) ranges an attached engine overwrites in every backward pass (see zero_grad)
         self._span = {k: (o, o + (p.numel() + al - 1) // al * al) for (k, p), o in zip(params, offs)}
         self._done = []          # [lo, hi) ranges already handed to an asynchronous all-reduce this step
         self._work = []
@@ -147,10 +148,29 @@ class FlatTrainer:
             # gradients accumulate through autograd
             m._mo_grad_out_st_gnn = self.grad_out('st_gnn.')
             m._mo_adam_now = self.adam_now if self.eager_adam else None
+            # ranges the engine overwrites in every backward pass (zero_grad skips them), merged
+            runs = []
+            for lo, hi in sorted(v for k, v in self._span.items() if not k.startswith('st_gnn.')):
+                if runs and lo <= runs[-1][1]:
+                    runs[-1][1] = max(runs[-1][1], hi)
+                else:
+                    runs.append([lo, hi])
+            self._overwritten = [tuple(r) for r in runs]
         return self
 
-    def zero_grad(self):
-        self.flat_g.zero_()
+    def zero_grad(self, full=False):
+        """Zero the flat gradient buffer.  After attach() on a Modified_UNET the UNet-side ranges are skipped unless
+        `full`: the engine OVERWRITES every one of those gradients in each backward pass (attach()), so the 330 MB fill of
+        config 3 -- 41 us at the head of every step's main stream -- only ever cleared values about to be replaced.  (A
+        step() without a backward pass in between then re-applies the previous gradients there instead of zeros.)"""
+        if full or not self._overwritten:
+            self.flat_g.zero_()
+            return
+        pos = 0
+        for lo, hi in self._overwritten + [(self.total, self.total)]:
+            if lo > pos:
+                self.flat_g[pos:lo].zero_()
+            pos = max(pos, hi)
 
     def ready_callback(self, prefix=''):
         """Callback for an engine: cb(names) announces that the gradients of `names` (without `prefix`) are final."""
