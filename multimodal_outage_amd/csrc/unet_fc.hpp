@@ -58,64 +58,74 @@ __device__ __forceinline__ void ufc_split8(const float (&w)[8], ub_bf8& hi, ub_b
   lo = __builtin_bit_cast(ub_bf8, make_uint4(l[0], l[1], l[2], l[3]));
 }
 
-template <int WMODE, int MB>             // MB: 16-row blocks of the few-row operand (P <= 16 * MB)
+// NBW: 16-column blocks of W per wave (a workgroup owns 64 NBW columns), KC: reduction elements per staged chunk.
+// <1, 128> was the first version: per (column, k) of W it stages 144 / 64 = 2.25 values of the few-row operand through
+// L2 -> LDS and reads every staged fragment from LDS once per 3 MFMAs -- the kernel scaled with the ROW count, not with
+// the weight bytes (134 rows 117 us, 536 rows 428 us on the 268 MB matrix).  <2, 64>: twice the columns per staged chunk
+// (half the L2 -> LDS traffic and half the LDS reads per MFMA) at the same registers (the chunk is half as long).
+template <int WMODE, int MB, int NBW, int KC>             // MB: 16-row blocks of the few-row operand (P <= 16 * MB)
 __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];      // [2][MB*16][UFC_LD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, lg = lane >> 4;
   constexpr int ROWS = MB * 16;
-  constexpr int NI = (ROWS * (UFC_KC / 8) + 255) / 256;                    // 16-byte pieces of a chunk per thread and half
+  constexpr int NS = KC / 32;                                              // MFMA steps per chunk
+  constexpr int NI = (ROWS * (KC / 8) + 255) / 256;                        // 16-byte pieces of a chunk per thread and half
   unsigned short* xh = xs;
   unsigned short* xl = xs + ROWS * UFC_LD;
-  const int c0 = (blockIdx.x * 4 + wave) * 16;                             // this wave's 16 output columns
-  const long r_begin = (long)blockIdx.y * a.chunks_per_split * UFC_KC;
-  const int nchunk = (int)min((long)a.chunks_per_split, (a.R - r_begin + UFC_KC - 1) / UFC_KC);
+  const int c0 = (blockIdx.x * 4 + wave) * 16 * NBW;                       // this wave's 16 NBW output columns
+  const long r_begin = (long)blockIdx.y * a.chunks_per_split * KC;
+  const int nchunk = (int)min((long)a.chunks_per_split, (a.R - r_begin + KC - 1) / KC);
   const __amdgpu_buffer_rsrc_t rh = ub_rsrc(a.ah, (long)a.P * a.R * 2), rl = ub_rsrc(a.al, (long)a.P * a.R * 2);
   const __amdgpu_buffer_rsrc_t rw = ub_rsrc(a.W, (long)a.R * a.C * 4);
 
   // More rows than 16 * MB (several windows per step): row groups of 16 * MB, one after the other INSIDE the workgroup -- its
-  // weight panel (64 columns x its share of the reduction, ~256 KB) is then re-read from L2 / the Infinity Cache instead of
-  // the whole 268 MB matrix being streamed from HBM once per group by separate launches.
-  // (WMODE 1 re-reads its panel by 4-byte column accesses: there the groups go into the grid instead -- blockIdx.z --
-  //  so that the groups of a panel run side by side: 4 windows 995 -> see DESIGN.md 5)
+  // weight panel (its columns x its share of the reduction, ~256 KB) is then re-read from L2 / the Infinity Cache instead of
+  // the whole 268 MB matrix being streamed from HBM once per group by separate launches (groups_in_grid: A/B switch).
   const int ngroups = (a.P + ROWS - 1) / ROWS;
   const int rg_first = a.groups_in_grid ? (int)blockIdx.z : 0, rg_last = a.groups_in_grid ? (int)blockIdx.z + 1 : ngroups;
   for (int rg = rg_first; rg < rg_last; ++rg) {
   const int prow = rg * ROWS;
-  ub_f4 acc[MB];
+  ub_f4 acc[NBW][MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) acc[mb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (ub_f4){0.f, 0.f, 0.f, 0.f};
 
-  // software pipeline as in unet_bf16.hpp: chunk ch+1's loads (weight fragments: 4 steps x 8 fp32 per lane; the few-row
-  // operand's 16-byte pieces) are issued in front of chunk ch's matrix work and wait in registers
-  float wreg[4][8];
+  // software pipeline as in unet_bf16.hpp: chunk ch+1's loads (weight fragments: NS steps x 8 fp32 per lane and column
+  // block; the few-row operand's 16-byte pieces) are issued in front of chunk ch's matrix work and wait in registers
+  float wreg[NBW][NS][8];
   ub_u4 xrh[NI], xrl[NI];
   int xsrc[NI], xdst[NI];                                                  // element offset in the operand (chunk 0) / in LDS
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int i = tid + 256 * it;
-    const int row = i / (UFC_KC / 8), seg = i - row * (UFC_KC / 8);
-    const bool ok = i < ROWS * (UFC_KC / 8);
+    const int row = i / (KC / 8), seg = i - row * (KC / 8);
+    const bool ok = i < ROWS * (KC / 8);
     xdst[it] = ok ? row * UFC_LD + 8 * seg : -1;
     xsrc[it] = (ok && row + prow < a.P) ? (row + prow) * a.R + 8 * seg : -1;
   }
   auto load_chunk = [&](const int ch) {
-    const long r0 = r_begin + (long)ch * UFC_KC;
+    const long r0 = r_begin + (long)ch * KC;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const long r = r0 + 32 * s + 8 * lg;                                 // first of this lane's 8 reduction indices
-      if (WMODE == 0) {                                                    // W[c0 + lp][r .. r+7]: 32 contiguous bytes
-        const bool ok = (c0 + lp) < a.C && r < a.R;                        // (R % 8 == 0)
-        const unsigned off = ok ? (unsigned)(((long)(c0 + lp) * a.R + r) * 4) : UB_OOB;
-        const ub_u4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0);
-        const ub_u4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(off + 16), 0, 0);
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int col = c0 + 16 * nb + lp;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { wreg[s][j] = __uint_as_float(u0[j]); wreg[s][4 + j] = __uint_as_float(u1[j]); }
-      } else {                                                             // W[r + j][c0 + lp]: 8 rows of the matrix
+      for (int s = 0; s < NS; ++s) {
+        const long r = r0 + 32 * s + 8 * lg;                               // first of this lane's 8 reduction indices
+        if (WMODE == 0) {                                                  // W[col][r .. r+7]: 32 contiguous bytes
+          const bool ok = col < a.C && r < a.R;                            // (R % 8 == 0)
+          const unsigned off = ok ? (unsigned)(((long)col * a.R + r) * 4) : UB_OOB;
+          const ub_u4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0);
+          const ub_u4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(off + 16), 0, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool ok = (c0 + lp) < a.C && (r + j) < a.R;
-          const unsigned off = ok ? (unsigned)(((r + j) * a.C + c0 + lp) * 4) : UB_OOB;
-          wreg[s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)off, 0, 0));
+          for (int j = 0; j < 4; ++j) { wreg[nb][s][j] = __uint_as_float(u0[j]); wreg[nb][s][4 + j] = __uint_as_float(u1[j]); }
+        } else {                                                           // W[r + j][col]: 8 rows of the matrix
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool ok = col < a.C && (r + j) < a.R;
+            const unsigned off = ok ? (unsigned)(((r + j) * a.C + col) * 4) : UB_OOB;
+            wreg[nb][s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)off, 0, 0));
+          }
         }
       }
     }
@@ -137,34 +147,43 @@ __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
         *reinterpret_cast<ub_u4*>(&xh[xdst[it]]) = xrh[it];
         *reinterpret_cast<ub_u4*>(&xl[xdst[it]]) = xrl[it];
       }
-    ub_bf8 wh[4], wl[4];
+    ub_bf8 wh[NBW][NS], wl[NBW][NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ufc_split8(wreg[s], wh[s], wl[s]);
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ufc_split8(wreg[nb][s], wh[nb][s], wl[nb][s]);
     __syncthreads();
     if (ch + 1 < nchunk) load_chunk(ch + 1);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int o = (mb * 16 + lp) * UFC_LD + 32 * s + 8 * lg;
         const ub_bf8 ah = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const ub_u4*>(&xh[o]));
         const ub_bf8 al = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const ub_u4*>(&xl[o]));
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[s], acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[s], acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[s], acc[mb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[nb][s], acc[nb][mb], 0, 0, 0);
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[nb][s], acc[nb][mb], 0, 0, 0);
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[nb][s], acc[nb][mb], 0, 0, 0);
+        }
       }
     }
   }
   // D[row = 4*lg + r][col = lp] of every block -> slab[ks][p][c]
   float* out = a.slab + (long)blockIdx.y * a.P * a.C;
-  if (c0 + lp < a.C) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int col = c0 + 16 * nb + lp;
+    if (col < a.C) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = prow + mb * 16 + 4 * lg + r;
-        if (p < a.P) out[(long)p * a.C + c0 + lp] = acc[mb][r];
-      }
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = prow + mb * 16 + 4 * lg + r;
+          if (p < a.P) out[(long)p * a.C + col] = acc[nb][mb][r];
+        }
+    }
   }
   __syncthreads();                                                         // (the next group restages the LDS operand)
   }

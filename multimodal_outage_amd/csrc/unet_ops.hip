@@ -27,7 +27,8 @@ static int mo_opt_no_mfma_wgrad = 0;     // A/B switch (mo_unet_set_option): 1 =
 static int mo_opt_no_mfma_conv = 0;      // 1 = deep-level convs on the im2col tile engine / VALU direct kernel as before
 static int mo_opt_no_bf16_mfma = 0;      // 1 = MO_BF_MATH requests run on the fp32 kernels (A/B switch)
 static int mo_opt_ub_min_w = 64;          // narrowest image the bf16 matrix-pipe conv serves (32: also the 32 x 32 level)
-static int mo_opt_fc_groups_grid = 0;     // FC row groups of 144: 0 = in the grid for the data gradient only, 1 = always, 2 = never
+static int mo_opt_fc_groups_grid = 0;     // FC row groups of 144: 1 = in the grid (blockIdx.z), else walked inside the workgroup
+static int mo_opt_fc_wide = 1;            // FC kernels: 1 = two 16-column blocks per wave, 64-element chunks; 0 = first version (A/B)
 static int mo_opt_ub_no_pack = 0;         // A/B switch: 1 = thin outputs on the unpacked D[pixel][co] kernel
 static int mo_opt_ub_ipw = 0;             // experiment: images per workgroup of the bf16 conv (0 = heuristic)
 static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
@@ -37,6 +38,7 @@ extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!strcmp(name, "no_mfma_conv")) { mo_opt_no_mfma_conv = value; return MO_OK; }
   if (!strcmp(name, "no_bf16_mfma")) { mo_opt_no_bf16_mfma = value; return MO_OK; }
   if (!strcmp(name, "ub_min_w")) { mo_opt_ub_min_w = value; return MO_OK; }
+  if (!strcmp(name, "fc_wide")) { mo_opt_fc_wide = value; return MO_OK; }
   if (!strcmp(name, "fc_groups_grid")) { mo_opt_fc_groups_grid = value; return MO_OK; }
   if (!strcmp(name, "ub_no_pack")) { mo_opt_ub_no_pack = value; return MO_OK; }
   if (!strcmp(name, "ub_ipw")) { mo_opt_ub_ipw = value; return MO_OK; }
@@ -895,8 +897,11 @@ extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int g
 // ------------------------------------------------------------------------------------------------
 // few-row Linear layers on the bf16 matrix pipe with 3 x bf16 split products (unet_fc.hpp)
 // ------------------------------------------------------------------------------------------------
+#define UFC_NBW 2                        // 16-column blocks of W per wave
+#define UFC_KC2 64                       // chunk length of the two-block kernel
+static int ufc_wide() { return mo_opt_fc_wide; }
 static void ufc_plan(long P, int R, int C, int& ks, int& cps) {
-  const int nx = mo_cdiv(C, 64), chunks = mo_cdiv(R, UFC_KC);
+  const int nx = mo_cdiv(C, ufc_wide() ? 64 * UFC_NBW : 64), chunks = mo_cdiv(R, ufc_wide() ? UFC_KC2 : UFC_KC);
   int want = 512 / nx; if (want < 1) want = 1; if (want > chunks) want = chunks;
   cps = mo_cdiv(chunks, want);
   ks = mo_cdiv(chunks, cps);
@@ -924,12 +929,15 @@ static int ufc_run(const float* a, long P, int R, const float* W, int C, const f
   const size_t lds = (size_t)2 * UFC_MB * 16 * UFC_LD * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ufc_kernel<WMODE, UFC_MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ufc_kernel<WMODE, UFC_MB, 1, UFC_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ufc_kernel<WMODE, UFC_MB, UFC_NBW, UFC_KC2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int ngroups = (int)mo_cdiv(P, (long)UFC_MB * 16);
-  A.groups_in_grid = ngroups > 1 && (mo_opt_fc_groups_grid == 1 || (mo_opt_fc_groups_grid == 0 && WMODE == 1));
-  hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB>), dim3(mo_cdiv(C, 64), ks, A.groups_in_grid ? ngroups : 1), dim3(256), lds, st, A);
+  A.groups_in_grid = ngroups > 1 && mo_opt_fc_groups_grid == 1;
+  const dim3 grid(mo_cdiv(C, ufc_wide() ? 64 * UFC_NBW : 64), ks, A.groups_in_grid ? ngroups : 1);
+  if (ufc_wide()) hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB, UFC_NBW, UFC_KC2>), grid, dim3(256), lds, st, A);
+  else hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB, 1, UFC_KC>), grid, dim3(256), lds, st, A);
   const long no = P * (long)C;
   hipLaunchKernelGGL(ufc_reduce_kernel, dim3(mo_cdiv(no, 256)), dim3(256), 0, st, slab, no, ks, bias, C, relu, out, no);
   return mo_launch_status();

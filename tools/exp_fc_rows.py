@@ -1,4 +1,4 @@
-"""FC 3 x bf16 kernels at several row counts (windows per step x 134), row groups inside the workgroup vs in the grid.
+"""FC 3 x bf16 kernels at several row counts (windows per step x 134), one vs two 16-column blocks of W per wave.
   python tools/exp_fc_rows.py"""
 import os
 import sys
@@ -30,10 +30,10 @@ for P in (134, 536, 1072):
         out = torch.empty(P, Co, device=dev); din = torch.empty(P, Ci, device=dev)
         ws3 = torch.empty(max(lib.mo_fc3_ws_floats(P, Ci, Co), lib.mo_fc3_ws_floats(P, Co, Ci)), device=dev)
         r = []
-        for mode in (2, 1):
-            L.call('mo_unet_set_option', b'fc_groups_grid', mode)
+        for mode in (0, 1):
+            L.call('mo_unet_set_option', b'fc_wide', mode)
             f3 = t(lambda: L.call('mo_fc3_fwd', L.ptr(x), P, Ci, L.ptr(W), L.ptr(b), Co, 1, L.ptr(out), L.ptr(ws3), L.stream()))
             d3 = t(lambda: L.call('mo_fc3_bwd_data', L.ptr(dout), P, Co, L.ptr(W), Ci, L.ptr(din), L.ptr(ws3), L.stream()))
             r.append((f3, d3))
-        L.call('mo_unet_set_option', b'fc_groups_grid', 0)
-        print(f'P {P:5d} W {Co}x{Ci}: groups in the workgroup: fwd {r[0][0]:7.1f} us dgrad {r[0][1]:7.1f} us | in the grid: fwd {r[1][0]:7.1f} dgrad {r[1][1]:7.1f}', flush=True)
+        L.call('mo_unet_set_option', b'fc_wide', 1)
+        print(f'P {P:5d} W {Co}x{Ci}: one column block per wave: fwd {r[0][0]:7.1f} us dgrad {r[0][1]:7.1f} us | two: fwd {r[1][0]:7.1f} dgrad {r[1][1]:7.1f}', flush=True)
