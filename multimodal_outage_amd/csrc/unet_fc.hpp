@@ -120,12 +120,13 @@ __global__ __launch_bounds__(256, 2) void ufc_kernel(UfcArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { wreg[nb][s][j] = __uint_as_float(u0[j]); wreg[nb][s][4 + j] = __uint_as_float(u1[j]); }
         } else {                                                           // W[r + j][col]: 8 rows of the matrix
+          // lane part of the address (row 8 lg, its column) in ONE register per column block, the row of the step and j
+          // as the wave-uniform scalar offset: per-load 64-bit address arithmetic made this variant spill (340 B / lane)
+          const unsigned voff = (col < a.C && r < a.R) ? (unsigned)((8 * lg * a.C + col) * 4) : UB_OOB;   // (R % 8 == 0)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const bool ok = col < a.C && (r + j) < a.R;
-            const unsigned off = ok ? (unsigned)(((r + j) * a.C + col) * 4) : UB_OOB;
-            wreg[nb][s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)off, 0, 0));
-          }
+          for (int j = 0; j < 8; ++j)
+            wreg[nb][s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rw, (int)voff, (int)((r0 + 32 * s + j) * a.C * 4), 0));
         }
       }
     }

@@ -899,9 +899,13 @@ extern "C" int mo_group_bn_finalize(const float* stats, long n_img, int C, int g
 // ------------------------------------------------------------------------------------------------
 #define UFC_NBW 2                        // 16-column blocks of W per wave
 #define UFC_KC2 64                       // chunk length of the two-block kernel
-static int ufc_wide() { return mo_opt_fc_wide; }
+// two column blocks per wave where there are columns and reduction length to spare (config 3: Encoder.fc1 both ways;
+// Decoder.fc2 -- 1024 x 16384 -- runs faster on the one-block kernel: 49 vs 55 us data gradient, 237 vs 288 us forward
+// at 8 windows)
+static bool ufc_wide(int R, int C) { return mo_opt_fc_wide && C >= 2048 && R >= 4096; }
 static void ufc_plan(long P, int R, int C, int& ks, int& cps) {
-  const int nx = mo_cdiv(C, ufc_wide() ? 64 * UFC_NBW : 64), chunks = mo_cdiv(R, ufc_wide() ? UFC_KC2 : UFC_KC);
+  const bool wide = ufc_wide(R, C);
+  const int nx = mo_cdiv(C, wide ? 64 * UFC_NBW : 64), chunks = mo_cdiv(R, wide ? UFC_KC2 : UFC_KC);
   int want = 512 / nx; if (want < 1) want = 1; if (want > chunks) want = chunks;
   cps = mo_cdiv(chunks, want);
   ks = mo_cdiv(chunks, cps);
@@ -935,8 +939,9 @@ static int ufc_run(const float* a, long P, int R, const float* W, int C, const f
   }
   const int ngroups = (int)mo_cdiv(P, (long)UFC_MB * 16);
   A.groups_in_grid = ngroups > 1 && mo_opt_fc_groups_grid == 1;
-  const dim3 grid(mo_cdiv(C, ufc_wide() ? 64 * UFC_NBW : 64), ks, A.groups_in_grid ? ngroups : 1);
-  if (ufc_wide()) hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB, UFC_NBW, UFC_KC2>), grid, dim3(256), lds, st, A);
+  const bool wide = ufc_wide(R, C);
+  const dim3 grid(mo_cdiv(C, wide ? 64 * UFC_NBW : 64), ks, A.groups_in_grid ? ngroups : 1);
+  if (wide) hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB, UFC_NBW, UFC_KC2>), grid, dim3(256), lds, st, A);
   else hipLaunchKernelGGL((ufc_kernel<WMODE, UFC_MB, 1, UFC_KC>), grid, dim3(256), lds, st, A);
   const long no = P * (long)C;
   hipLaunchKernelGGL(ufc_reduce_kernel, dim3(mo_cdiv(no, 256)), dim3(256), 0, st, slab, no, ks, bias, C, relu, out, no);
