@@ -613,3 +613,38 @@ def test_eager_adam_gives_the_same_parameters():
             assert len(calls) >= 9 and sum(hi - lo for lo, hi in calls) == 3 * tr.total     # every range exactly once per step
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+def test_trainer_zero_grad_skips_what_the_engine_overwrites():
+    """FlatTrainer.attach() on a Modified_UNET: the engine overwrites every UNet-side gradient in each backward pass, so
+    zero_grad() only clears the Graph WaveNet's ranges (which may accumulate through autograd) -- and three steps with the
+    lazy zero_grad leave bit-identical parameters to three steps with a full clear in front of every backward pass."""
+    from multimodal_outage_amd.trainer import FlatTrainer
+    x = rand(911, (1, 67, 2, 1, 128, 128)).cuda()
+    tdim = rand(913, (1, 67, 2, 64)).cuda()
+    tgt = rand(912, (1, 67, 2, 1, 128, 128)).cuda()
+    res = {}
+    for full in (True, False):
+        m = _model().train()
+        tr = FlatTrainer(m, lr=1e-3).attach()
+        assert tr._overwritten and all(lo < hi for lo, hi in tr._overwritten)
+        for _ in range(3):
+            tr.zero_grad(full=full)
+            F.mse_loss(m(x, tdim), tgt).backward()
+            tr.allreduce()
+            tr.step()
+        torch.cuda.synchronize()
+        res[full] = tr.flat_p.clone()
+        # the lazy form leaves the engine's ranges alone and clears the rest
+        tr.flat_g.fill_(3.0)
+        tr.zero_grad()
+        g = tr.flat_g.cpu()
+        covered = torch.zeros(tr.total, dtype=torch.bool)
+        for lo, hi in tr._overwritten:
+            covered[lo:hi] = True
+        assert bool((g[covered] == 3.0).all()) and bool((g[~covered] == 0.0).all())
+        lo, hi = tr._span[next(k for k in tr._span if k.startswith('st_gnn.'))]
+        assert not bool(covered[lo:hi].any())
+        tr.zero_grad(full=True)
+        assert float(tr.flat_g.abs().sum()) == 0.0
+    assert torch.equal(res[True], res[False])

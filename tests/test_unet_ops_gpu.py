@@ -315,12 +315,14 @@ def test_dropout_mask(L):
 
 @pytest.mark.parametrize('P,K,N', [(134, 16384, 4096), (134, 1024, 16384), (7, 256, 128), (144, 4096, 264), (33, 520, 72),
                                    # several windows per step: row groups of 144 walked inside the kernel (ragged last group)
-                                   (536, 16384, 4096), (300, 1024, 520), (145, 256, 128)])
+                                   (536, 16384, 4096), (300, 1024, 520), (145, 256, 128),
+                                   # ragged shapes on the two-column-block kernel (>= 2048 columns, >= 4096 reduction)
+                                   (150, 4104, 2056), (20, 2056, 4104)])
 def test_fc_three_way_bf16_split(L, P, K, N):
     """mo_fc3_fwd / mo_fc3_bwd_data (csrc/unet_fc.hpp): few-row Linear layers with "3 x bf16" split products on the bf16
     matrix pipe against the float64 product: 5e-5 of the result's scale (a plain bf16 product would sit at ~2e-3);
-    ragged row counts, reduction lengths that are not a multiple of the 128-element chunk, column counts that are not a
-    multiple of a workgroup's 64."""
+    ragged row counts, reduction lengths that are not a multiple of the 128- / 64-element chunk, column counts that are not
+    a multiple of a workgroup's 64 / 128."""
     lib = L.load()
     x = rand(31, (P, K)); W = rand(32, (N, K)) / np.sqrt(K); b = rand(33, (N,)); dout = rand(34, (P, N))
     xd, Wd, bd, dd = dev(x), dev(W), dev(b), dev(dout)
