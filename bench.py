@@ -43,7 +43,7 @@ def pmc_traffic(dtype, batch):
     (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
     command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950).
     None when no pass matches this dtype/batch."""
-    for f in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):      # the latest round's passes first
+    for f in ('r03b_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):      # the latest round's passes first
         try:
             e = json.load(open(os.path.join(ROOT, 'profiles', f))).get(f'{dtype}_b{batch}')
             if e:
@@ -126,7 +126,7 @@ def unet_pmc_traffic(batch, horizon, cin, size):
     leg's shape is not the profiled one."""
     if (batch, horizon, cin, size) != (1, 2, 13, 256):
         return None
-    for f in ('r03_unet_c3_pmc_traffic.json', 'r02_unet_c3_pmc_traffic.json'):
+    for f in ('r03b_unet_c3_pmc_traffic.json', 'r03_unet_c3_pmc_traffic.json', 'r02_unet_c3_pmc_traffic.json'):
         try:
             return json.load(open(os.path.join(ROOT, 'profiles', f)))['bytes_per_step']
         except Exception:

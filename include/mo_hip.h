@@ -394,7 +394,14 @@ int mo_fc3_bwd_weight(const float* dout, long P, int N, const float* x, int C, f
 int mo_raster_prepare(const float* raw, long n, int h, int w, float fill_value, float mean, float std, float* out,
                       int oh, int ow, void* stream);
 
-/* A/B switches of the UNet kernels for measurements: "no_mfma_wgrad" (1: the VALU / split-K 3x3 weight gradients) */
+/* A/B switches of the UNet kernels for measurements (defaults are the product path):
+ *   "no_mfma_wgrad" 1: the VALU / split-K 3x3 weight gradients;  "no_mfma_conv" 1: deep-level convs on the tile engine;
+ *   "no_bf16_mfma" 1: MO_BF_MATH requests on the fp32 kernels;   "ub_min_w" 32: the 32 x 32 level on the bf16 conv too;
+ *   "ux_min_co": smallest output-channel count on the fp32 matrix-pipe conv;
+ *   "ub_no_pack" 1: thin outputs (Co <= 8) on the unpacked D[pixel][co] kernel;  "ub_ipw" n: images per workgroup;
+ *   "fc_wide" 0: one 16-column block of W per wave in the 3 x bf16 FC kernels;  "fc_groups_grid" 1: FC row groups in
+ *   the grid instead of inside the workgroup.
+ * The dense ring GEMM reads MO_GEMM_MFMA=32 from the environment once (v_mfma_f32_32x32x16_bf16 instead of 16x16x32). */
 int mo_unet_set_option(const char* name, int value);
 
 /* ---- data-parallel exchange step: gradient all-reduce over RCCL / xGMI ---------------------------------

@@ -43,7 +43,7 @@ def timeit(fn, reps=a.reps):
 LAYERS = [(13, 0, 0, 4, 256), (4, 1, 0, 4, 256), (4, 1, 4, 4, 256), (4, 1, 0, 8, 128), (8, 1, 0, 8, 128), (8, 1, 8, 8, 128),
           (8, 1, 0, 16, 64), (16, 1, 0, 16, 64), (16, 1, 16, 16, 64),
           # deep levels (exact-fp32 matrix pipe in both modes)
-          (16, 1, 0, 32, 32), (32, 1, 0, 32, 32), (32, 1, 32, 32, 32), (32, 1, 0, 64, 16), (64, 1, 0, 64, 16)]
+          (16, 1, 0, 32, 32), (32, 0, 0, 32, 32), (32, 0, 32, 32, 32), (32, 0, 0, 64, 16), (64, 0, 0, 64, 16)]
 print(f'{"layer":26s} {"op":6s} {"fp32 us":>9s} {"bf16-mfma us":>13s} {"MB":>8s} {"TB/s (mfma)":>12s}')
 if a.layers:
     LAYERS = [LAYERS[int(i)] for i in a.layers.split(',')]
@@ -91,7 +91,10 @@ for C0, bf0, C1, Co, S in LAYERS:
                            ('wgrad', wgrad, in_bytes + px * Co * 2)):
         if op not in a.only.split(','):
             continue
-        t0 = timeit(mk(0))
+        try:
+            t0 = timeit(mk(0))
+        except RuntimeError as e:                    # (a storage combination the fp32 kernels do not serve)
+            t0 = float('nan')
         try:
             t1 = timeit(mk(1))
         except RuntimeError as e:                    # (entry point does not know MO_BF_MATH yet)
