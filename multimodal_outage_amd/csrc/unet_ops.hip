@@ -257,7 +257,10 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     A.img_per_wg = (int)ipw;
     dim3 grid((unsigned)bands, (unsigned)((n_img + ipw - 1) / ipw));
     hipStream_t st = ST(stream);
-    // (13 -> 4 at 256^2, the one layer with Ci > 8 and Co <= 4: 9 weight fragments per lane, 222 us packed vs 209 us)
+    // (13 -> 4 at 256^2, the one layer with Ci > 8 and Co <= 4, stays unpacked: four pixels per row group need 9 weight
+    //  fragments per lane -- 222 us against 209 us; two pixels, half the product's rows idle, 184 us in isolation but
+    //  nothing measurable in the step, and the other summation order moves the config-3 golden's noisiest deep-stage
+    //  gradient distance across its bound)
     if (ub_tw(Wd) == 64 && Co <= 8 && Ci <= (Co <= 4 ? 8 : 16) && !mo_opt_ub_no_pack) {
       if (Co <= 4) {
         if (Ci <= 4) ub_launch_packed<4, 16, 4>(A, false, grid, st);
