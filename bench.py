@@ -521,7 +521,7 @@ def main():
     ser_ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1) in prof_serial)
     ser_ach = sum(f for (_, f, _, _) in prof_serial) / (ser_ms * 1e-3) / 1e12 if ser_ms > 0 else 0.0
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
-    kname = ("gemm_bf16_256_kernel<256x256x32, 4-stage LDS-DMA ring, mfma_f32_32x32x16_bf16>" if args.dtype == 'bf16'
+    kname = ("gemm_bf16_256_kernel<256x256x32, 4-stage LDS-DMA ring, mfma_f32_16x16x32_bf16>" if args.dtype == 'bf16'
              else "mo_gemm_kernel<128,128,16, mfma_f32_32x32x2_f32>")
     roofline = {"bound": "mfma", "kernel": kname + " dense adaptive-adjacency node-axis product "
                                                    "(forward, data-gradient and dA launches)",
