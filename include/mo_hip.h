@@ -30,7 +30,7 @@ const char* mo_strerror(int code);
 /* Bumped whenever an existing entry point changes its argument list (a stale libmo_hip.so called through a newer ctypes
  * table would silently misread its arguments): _lib.load() refuses a library whose mo_version() differs from
  * _lib.ABI_VERSION.  3 = round 3 (mo_nchw_to_nbtc/mo_nbtc_to_nchw node_new, UNet `dtypes` words, ...). */
-#define MO_ABI_VERSION 4
+#define MO_ABI_VERSION 5
 int mo_version(void);
 /* tuning switches for A/B measurements: "persist" (1: persistent skinny-K kernels; 0, default: one workgroup per tile) */
 int mo_set_option(const char* name, int value);
@@ -323,14 +323,19 @@ int mo_outc_loss_bwd(const float* in, long istride, int Ci, const float* sc, con
                      long n_img, int HW, float* ws, const float* scale, float* dW, float* db,
                      int dtypes /* MO_BF_IN0 */, void* stream);
 /* Up.up (unet.py:71): ConvTranspose2d(Ci, Co, k=2, s=2) with bias; W (Ci, Co, 2, 2); H,Wd = input size */
+/* dtypes (ABI 5): MO_BF_IN0 the input view, MO_BF_OUT the upsampled result, MO_BF_DY the gradient w.r.t. it stored as bf16
+ * -- served by the streaming kernels only (mo_convt2x2_bf16_route(Ci, Co, n_img) == 1: Ci <= 16, Co <= 8), else
+ * MO_EUNSUPPORTED.  The bf16 mode stores the upsampled map of the three large levels and the concat gradient behind it
+ * as bf16: the concat conv rounds its operands to bf16 anyway, so its forward result is bit-identical. */
+int mo_convt2x2_bf16_route(int Ci, int Co, long n_img);
 int mo_convt2x2_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                     int gsize, const float* W, const float* b, int Co, long n_img, int H, int Wd, float* out,
-                    long ostride, void* stream);
+                    long ostride, int dtypes, void* stream);
 int mo_convt2x2_bwd_data(const float* dout, long dostride, int Co, const float* W, int Ci, long n_img, int H,
-                         int Wd, float* din, long distride, void* stream);
+                         int Wd, float* din, long distride, int dtypes, void* stream);
 int mo_convt2x2_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride, int Ci,
                            const float* sc, const float* sh, int relu, int gsize, long n_img, int H, int Wd,
-                           float* dW, float* db /* bias gradient, may be NULL */, float* ws, void* stream);
+                           float* dW, float* db /* bias gradient, may be NULL */, float* ws, int dtypes, void* stream);
 /* BatchNorm2d statistics (unet.py:45,48): stats[img][c] = (sum, sumsq) over HW */
 int mo_nchw_stats(const float* y, long istride, int C, long n_img, int HW, float* stats, void* stream);
 /* per-group finalize: scale/shift/mean/rstd [G][C]; running stats receive G sequential momentum updates

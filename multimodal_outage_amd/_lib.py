@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmo_hip.so')
 
 _lib = None
-ABI_VERSION = 4          # == MO_ABI_VERSION of include/mo_hip.h; bump both when an entry point's arguments change
+ABI_VERSION = 5          # == MO_ABI_VERSION of include/mo_hip.h; bump both when an entry point's arguments change
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
 
@@ -84,9 +84,10 @@ SIGNATURES = {
     'mo_nchw_conv1x1_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, vp, i64, i32, vp]),
     'mo_nchw_conv1x1_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, vp, i64, i32, vp]),
     'mo_nchw_conv1x1_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, vp, vp, vp, i32, vp]),
-    'mo_convt2x2_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, i32, vp, i64, vp]),
-    'mo_convt2x2_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, i32, vp, i64, vp]),
-    'mo_convt2x2_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp]),
+    'mo_convt2x2_bf16_route': (i32, [i32, i32, i64]),
+    'mo_convt2x2_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, i32, i64, i32, i32, vp, i64, i32, vp]),
+    'mo_convt2x2_bwd_data': (i32, [vp, i64, i32, vp, i32, i64, i32, i32, vp, i64, i32, vp]),
+    'mo_convt2x2_bwd_weight': (i32, [vp, i64, i32, vp, i64, i32, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, i32, vp]),
     'mo_fc3_supported': (i32, [i64, i32, i32]),
     'mo_fc3_ws_floats': (i64, [i64, i32, i32]),
     'mo_fc3_fwd': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp, vp]),

@@ -643,15 +643,19 @@ static bool utt_ok(const float* a, long as, const float* b, long bs, int Ci, int
   return Ci <= 16 && Co <= 8 && n_img <= 65535 && (((uintptr_t)a) & 15) == 0 && (((uintptr_t)b) & 15) == 0 &&
          (as & 3) == 0 && (bs & 3) == 0;
 }
+// the streaming ConvTranspose2d kernels (and only they) read / write bf16 tensors: MO_BF_IN0 the input view, MO_BF_OUT the
+// upsampled result, MO_BF_DY the gradient w.r.t. it
+extern "C" int mo_convt2x2_bf16_route(int Ci, int Co, long n_img) { return Ci <= 16 && Co <= 8 && n_img > 0 && n_img <= 65535; }
 extern "C" int mo_convt2x2_fwd(const float* in, long istride, int Ci, const float* sc, const float* sh, int relu,
                                int gsize, const float* W, const float* b, int Co, long n_img, int H, int Wd,
-                               float* out, long ostride, void* stream) {
+                               float* out, long ostride, int dtypes, void* stream) {
   MO_CHECK_ARG(in && W && out && Ci > 0 && Co > 0 && n_img > 0 && (Wd % 4) == 0);
   const long P = n_img * H * Wd;
   MO_CHECK_ARG(P < (1L << 31));
   if (utt_ok(in, istride, out, ostride, Ci, Co, n_img) && b) {
     UtTArgs a = {};
-    a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize; a.bfi = 0;
+    a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize;
+    a.bfi = (dtypes & MO_BF_IN0) != 0; a.bfo = (dtypes & MO_BF_OUT) != 0;
     a.W = W; a.b = b; a.out = out; a.os = ostride; a.Co = Co; a.n_img = n_img; a.H = H; a.Wd = Wd;
     int gx = mo_cdiv((long)H * (Wd / 4), 256); if (gx > 64) gx = 64;
     dim3 grid(gx, (unsigned)n_img);
@@ -659,6 +663,7 @@ extern "C" int mo_convt2x2_fwd(const float* in, long istride, int Ci, const floa
     else hipLaunchKernelGGL((ut_convt_fwd_kernel<8>), grid, dim3(256), 0, ST(stream), a);
     return mo_launch_status();
   }
+  if (dtypes & (MO_BF_IN0 | MO_BF_OUT)) return MO_EUNSUPPORTED;                    // (bf16 storage: mo_convt2x2_bf16_route)
   MoOperand A = uplain(W, 4 * Co, Ci, 4 * Co);                                    // KROWS rows = k = ci, cols = m = (co,ky,kx)
   MoOperand B; uop(B, Ci, P); useg(B.seg[0], in, istride, sc, sh, relu);           // NCHW KROWS
   MoEpi E; uepi(E, out, ostride); E.bias = b;
@@ -666,12 +671,13 @@ extern "C" int mo_convt2x2_fwd(const float* in, long istride, int Ci, const floa
   return ulaunch_fwd<MO_KROWS, MO_EPI_CONVT, MO_SRC_PLAIN, MO_SRC_NCHW>(A, B, E, G, 4 * Co, P, ST(stream));
 }
 extern "C" int mo_convt2x2_bwd_data(const float* dout, long dostride, int Co, const float* W, int Ci, long n_img, int H,
-                                    int Wd, float* din, long distride, void* stream) {
+                                    int Wd, float* din, long distride, int dtypes, void* stream) {
   MO_CHECK_ARG(dout && W && din && Ci > 0 && Co > 0 && n_img > 0 && (Wd % 4) == 0);
   const long P = n_img * H * Wd;
   if (utt_ok(dout, dostride, din, distride, Ci, Co, n_img)) {
     UtTArgs a = {};
     a.W = W; a.Ci = Ci; a.Co = Co; a.out = din; a.os = distride; a.dout = dout; a.dos = dostride;
+    a.bfd = (dtypes & MO_BF_DY) != 0;
     a.n_img = n_img; a.H = H; a.Wd = Wd;
     int gx = mo_cdiv((long)H * (Wd / 4), 256); if (gx > 64) gx = 64;
     dim3 grid(gx, (unsigned)n_img);
@@ -679,6 +685,7 @@ extern "C" int mo_convt2x2_bwd_data(const float* dout, long dostride, int Co, co
     else hipLaunchKernelGGL((ut_convt_bwd_data_kernel<16>), grid, dim3(256), 0, ST(stream), a);
     return mo_launch_status();
   }
+  if (dtypes & MO_BF_DY) return MO_EUNSUPPORTED;
   MoOperand A = uplain(W, 4 * Co, Ci, 4 * Co);                                    // XROWS rows = m = ci, cols = k = (co,ky,kx)
   MoOperand B; uop(B, 4 * Co, P); useg(B.seg[0], dout, dostride, nullptr, nullptr, 0);   // CONVT KROWS
   MoEpi E; uepi(E, din, distride);
@@ -687,12 +694,13 @@ extern "C" int mo_convt2x2_bwd_data(const float* dout, long dostride, int Co, co
 }
 extern "C" int mo_convt2x2_bwd_weight(const float* dout, long dostride, int Co, const float* in, long istride, int Ci,
                                       const float* sc, const float* sh, int relu, int gsize, long n_img, int H, int Wd,
-                                      float* dW, float* db, float* ws, void* stream) {
+                                      float* dW, float* db, float* ws, int dtypes, void* stream) {
   MO_CHECK_ARG(dout && in && dW && ws && Ci > 0 && Co > 0 && n_img > 0 && (Wd % 4) == 0);
   const long P = n_img * H * Wd;
   if (utt_ok(dout, dostride, in, istride, Ci, Co, n_img) && Ci >= Co) {
     UtTArgs a = {};
-    a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize; a.bfi = 0;
+    a.in = in; a.is = istride; a.Ci = Ci; a.sc = sc; a.sh = sh; a.relu = relu; a.gsize = gsize < 1 ? 1 : gsize;
+    a.bfi = (dtypes & MO_BF_IN0) != 0; a.bfd = (dtypes & MO_BF_DY) != 0;
     a.Co = Co; a.dout = dout; a.dos = dostride; a.slab = ws; a.n_img = n_img; a.H = H; a.Wd = Wd;
     int gx = mo_cdiv((long)H * (Wd / 4), 256); if (gx > 8) gx = 8;
     long ipw = (n_img * gx + UD_MAX_SLABS - 1) / UD_MAX_SLABS; if (ipw < 1) ipw = 1;
@@ -708,6 +716,7 @@ extern "C" int mo_convt2x2_bwd_weight(const float* dout, long dostride, int Co, 
     if (db) hipLaunchKernelGGL(uslab_reduce_kernel, dim3(mo_cdiv(Co, 32)), dim3(1024), 0, st, ws + nw, nrow, nz, db, (long)Co);
     return mo_launch_status();
   }
+  if (dtypes & (MO_BF_IN0 | MO_BF_DY)) return MO_EUNSUPPORTED;
   if (db) {       // general path: the bias gradient is the per-channel sum of dout (ws reuse is stream-ordered)
     int rc = mo_nchw_channel_sum(dout, dostride, Co, n_img, 4 * H * Wd, db, ws, stream);
     if (rc) return rc;

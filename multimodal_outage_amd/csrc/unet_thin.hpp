@@ -136,12 +136,24 @@ __global__ __launch_bounds__(256) void ut_wgrad1x1_kernel(UtWgArgs a) {
 struct UtTArgs {
   const float* in; long is; int Ci;                      // input view (H x W), optional folded affine + ReLU, fp32 | bf16
   const float* sc; const float* sh; int relu, gsize, bfi;
+  int bfo, bfd;                                          // forward result / the gradient w.r.t. it stored as bf16
   const float* W; const float* b;                        // (Ci, Co, 2, 2), (Co)
   float* out; long os; int Co;                           // fp32, (2H x 2W); for the data gradient: `out` is din (H x W)
   const float* dout; long dos;                           // data / weight gradient: gradient w.r.t. out
   float* slab;                                           // weight gradient: [rows][Ci*Co*4 + Co]
   long n_img; int H, Wd, img_per_wg, cic;
 };
+// 8 consecutive elements of an fp32 | bf16 tensor
+__device__ __forceinline__ void ut_ld8(const float* base, long idx, int bf, float (&e)[8]) {
+  if (bf) {
+    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    e[0] = ua_lo(u.x); e[1] = ua_hi(u.x); e[2] = ua_lo(u.y); e[3] = ua_hi(u.y);
+    e[4] = ua_lo(u.z); e[5] = ua_hi(u.z); e[6] = ua_lo(u.w); e[7] = ua_hi(u.w);
+  } else {
+    const float4 d0 = *reinterpret_cast<const float4*>(base + idx), d1 = *reinterpret_cast<const float4*>(base + idx + 4);
+    e[0] = d0.x; e[1] = d0.y; e[2] = d0.z; e[3] = d0.w; e[4] = d1.x; e[5] = d1.y; e[6] = d1.z; e[7] = d1.w;
+  }
+}
 template <int CO>
 __global__ __launch_bounds__(256) void ut_convt_fwd_kernel(UtTArgs a) {
   __shared__ float wsm[16][CO * 4 + 1];
@@ -187,9 +199,16 @@ __global__ __launch_bounds__(256) void ut_convt_fwd_kernel(UtTArgs a) {
       if (co < a.Co)
 #pragma unroll
         for (int ky = 0; ky < 2; ++ky) {
-          float* o = a.out + img * a.os + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x;
-          *reinterpret_cast<float4*>(o) = make_float4(acc[co][2 * ky][0], acc[co][2 * ky + 1][0], acc[co][2 * ky][1], acc[co][2 * ky + 1][1]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(acc[co][2 * ky][2], acc[co][2 * ky + 1][2], acc[co][2 * ky][3], acc[co][2 * ky + 1][3]);
+          const long oe = img * a.os + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x;
+          if (a.bfo) {                                    // 8 consecutive pixels of the (2H x 2W) row: 16 bytes of bf16
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.out) + oe) =
+                make_uint4(ua_pack2(acc[co][2 * ky][0], acc[co][2 * ky + 1][0]), ua_pack2(acc[co][2 * ky][1], acc[co][2 * ky + 1][1]),
+                           ua_pack2(acc[co][2 * ky][2], acc[co][2 * ky + 1][2]), ua_pack2(acc[co][2 * ky][3], acc[co][2 * ky + 1][3]));
+          } else {
+            float* o = a.out + oe;
+            *reinterpret_cast<float4*>(o) = make_float4(acc[co][2 * ky][0], acc[co][2 * ky + 1][0], acc[co][2 * ky][1], acc[co][2 * ky + 1][1]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(acc[co][2 * ky][2], acc[co][2 * ky + 1][2], acc[co][2 * ky][3], acc[co][2 * ky + 1][3]);
+          }
         }
   }
 }
@@ -215,9 +234,8 @@ __global__ __launch_bounds__(256) void ut_convt_bwd_data_kernel(UtTArgs a) {
     for (int co = 0; co < a.Co; ++co)
 #pragma unroll
       for (int ky = 0; ky < 2; ++ky) {
-        const float* d = a.dout + img * a.dos + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x;
-        const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + 4);
-        const float e[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};      // (pixel p, kx) = e[2p + kx]
+        float e[8];                                          // (pixel p, kx) = e[2p + kx]
+        ut_ld8(a.dout, img * a.dos + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x, a.bfd, e);
 #pragma unroll
         for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
@@ -274,9 +292,8 @@ __global__ __launch_bounds__(256) void ut_convt_wgrad_kernel(UtTArgs a) {
         if (co < a.Co)
 #pragma unroll
           for (int ky = 0; ky < 2; ++ky) {
-            const float* d = a.dout + img * a.dos + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x;
-            const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + 4);
-            const float e[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float e[8];
+            ut_ld8(a.dout, img * a.dos + ((long)co * 2 * a.H + 2 * y + ky) * W2 + 2 * x, a.bfd, e);
             accb[co] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
 #pragma unroll
             for (int kx = 0; kx < 2; ++kx)

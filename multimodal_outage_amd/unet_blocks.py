@@ -89,7 +89,7 @@ class UpFn(torch.autograd.Function):
         H2, W2 = x2.shape[2], x2.shape[3]
         u = _empty(n, C0, 2 * H, 2 * W, dev=dev)
         L.call('mo_convt2x2_fwd', L.ptr(x1), Ci * H * W, Ci, None, None, 0, gs, L.ptr(p[cfg.pre + '.up.weight']),
-               L.ptr(p[cfg.pre + '.up.bias']), C0, n, H, W, L.ptr(u), C0 * 4 * H * W, L.stream())
+               L.ptr(p[cfg.pre + '.up.bias']), C0, n, H, W, L.ptr(u), C0 * 4 * H * W, 0, L.stream())
         pad = None
         if (H2, W2) != (2 * H, 2 * W):
             # unet.py:76-81: the upsampled map is zero-padded (or cropped: F.pad takes negative widths) to the skip map's
@@ -126,9 +126,9 @@ class UpFn(torch.autograd.Function):
                          dtype=torch.float32)
         dbt = grads.buf(cfg.pre + '.up.bias', (C0,))
         L.call('mo_convt2x2_bwd_weight', du.data_ptr(), dus, C0, L.ptr(ctx.x1), Ci * H * W, Ci, None, None, 0, gs, n, H, W,
-               L.ptr(dWt), L.ptr(dbt), L.ptr(ws), st)
+               L.ptr(dWt), L.ptr(dbt), L.ptr(ws), 0, st)
         dx1 = _empty(n, Ci, H, W, dev=dev)
-        L.call('mo_convt2x2_bwd_data', du.data_ptr(), dus, C0, L.ptr(Wt), Ci, n, H, W, L.ptr(dx1), Ci * H * W, st)
+        L.call('mo_convt2x2_bwd_data', du.data_ptr(), dus, C0, L.ptr(Wt), Ci, n, H, W, L.ptr(dx1), Ci * H * W, 0, st)
         return (None, dx1, dx2) + grads.result(cfg.names)
 
 
@@ -245,7 +245,7 @@ class ExpansionFn(torch.autograd.Function):
             u = _empty(n, ci // 2, 2 * H, 2 * H, dev=dev)
             L.call('mo_convt2x2_fwd', L.ptr(v.t), v.istride, ci, L.ptr(v.sc), L.ptr(v.sh), 1 if v.sc is not None else 0,
                    gs, L.ptr(p[f'up{k}.up.weight']), L.ptr(p[f'up{k}.up.bias']), ci // 2, n, H, H, L.ptr(u),
-                   (ci // 2) * 4 * H * H, st)
+                   (ci // 2) * 4 * H * H, 0, st)
             sk = skips[4 - k]
             if sk.H != 2 * H:
                 raise NotImplementedError('Up padding (unet.py:76-81) is only needed for odd sizes')
@@ -295,9 +295,9 @@ class ExpansionFn(torch.autograd.Function):
                               dtype=torch.float32)
             dbt = grads.buf(f'up{k}.up.bias', (C0,))
             L.call('mo_convt2x2_bwd_weight', du.data_ptr(), dus, C0, L.ptr(vin.t), vin.istride, ci, L.ptr(vin.sc),
-                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(dbt), L.ptr(wsu), st)
+                   L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(dbt), L.ptr(wsu), 0, st)
             da = _empty(n, ci, H, H, dev=dev)
-            L.call('mo_convt2x2_bwd_data', du.data_ptr(), dus, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
+            L.call('mo_convt2x2_bwd_data', du.data_ptr(), dus, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, 0, st)
         return (None, da, dfm[0], dfm[1], dfm[2], dfm[3]) + grads.result(cfg.names)
 
 

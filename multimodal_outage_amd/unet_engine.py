@@ -480,10 +480,17 @@ class UnetDecodeFn(torch.autograd.Function):
         ups = []
         for k, (ci, co) in enumerate(DEC_CH, 1):
             H = v.H
-            u = _empty(n, ci // 2, 2 * H, 2 * H, dev=dev)
+            # bf16 mode, the levels whose ConvTranspose2d runs on the streaming kernels (up3, up4): the upsampled map -- and in backward the concat gradient behind it -- is
+            # stored as bf16.  The concat conv and its weight gradient round their operands to bf16 on the way into the
+            # MFMA anyway, so the forward result is bit-identical; per window this takes 0.37 GB (u: one write, two reads)
+            # and 0.6 GB (the gradient: written by the concat conv's data gradient, read by the skip side's activation
+            # backward and by ConvTranspose2d's two gradients) off the step's 18 GB.
+            ubf = bool(bf_ok(state.get('act_dtype', 'f32'), co, 2 * H, 2 * H) and not GRAD_F32 and
+                       L.load().mo_convt2x2_bf16_route(ci, ci // 2, n))
+            u = _empty(n, ci // 2, 2 * H, 2 * H, dev=dev, bf=ubf)
             L.call('mo_convt2x2_fwd', L.ptr(v.t), v.istride, ci, L.ptr(v.sc), L.ptr(v.sh), 1 if v.sc is not None else 0,
                    gs, L.ptr(p[f'expansion.up{k}.up.weight']), L.ptr(p[f'expansion.up{k}.up.bias']), ci // 2, n, H, H,
-                   L.ptr(u), (ci // 2) * 4 * H * H, st)
+                   L.ptr(u), (ci // 2) * 4 * H * H, (L.BF_IN0 * v.bf) | (L.BF_OUT * int(ubf)), st)
             sk = skips[4 - k]
             if sk.H != 2 * H:
                 raise NotImplementedError('Up padding (unet.py:76-81) inside Modified_UNET: only reached by image sizes that '
@@ -495,7 +502,7 @@ class UnetDecodeFn(torch.autograd.Function):
             sv, vn = double_conv_fwd(p, f'expansion.up{k}.conv', [sk, View(u, ci // 2, 2 * H, 2 * H)], co, n, gs,
                                      training, bufs, dev, bf=(bk, bk and k == 4),
                                      math=state.get('act_dtype', 'f32') == 'bf16')
-            ups.append(dict(vin=v, dc=sv, ci=ci, H=H))
+            ups.append(dict(vin=v, dc=sv, ci=ci, H=H, ubf=ubf))
             v = vn
         Wo, bo = p['expansion.outc.conv.weight'], p['expansion.outc.conv.bias']
         Cout = Wo.shape[0]
@@ -570,8 +577,9 @@ class UnetDecodeFn(torch.autograd.Function):
         for k in (4, 3, 2, 1):
             up = ctx.ups[k - 1]
             ci, H, vin = up['ci'], up['H'], up['vin']
-            dcat = double_conv_bwd(p, up['dc'], n, gs, grads, dev, da=da, dp=None, lane=lane,
+            dcat = double_conv_bwd(p, up['dc'], n, gs, grads, dev, da=da, dp=None, lane=lane, dx_bf=up['ubf'],
                                    da_scale=loss_scale if k == 4 else None)     # (n, ci, 2H, 2H)
+            dyf = L.BF_DY * _is_bf(dcat)
             C0 = ci // 2
             dfm[4 - k] = dcat[:, :C0]
             du = dcat[:, C0:]
@@ -580,15 +588,16 @@ class UnetDecodeFn(torch.autograd.Function):
             dWt = grads.buf(f'expansion.up{k}.up.weight', Wt.shape)
             dbt = grads.buf(f'expansion.up{k}.up.bias', (C0,))
 
-            def convt_wgrad(ls, du=du, du_stride=du_stride, C0=C0, vin=vin, ci=ci, H=H, dWt=dWt, dbt=dbt):
+            def convt_wgrad(ls, du=du, du_stride=du_stride, C0=C0, vin=vin, ci=ci, H=H, dWt=dWt, dbt=dbt, dyf=dyf):
                 wsu = lane.keep(torch.empty(max(lib.mo_unet_wgrad_ws_floats(ci, 4 * C0, n * H * H), n * C0 * 2), device=dev,
                                             dtype=torch.float32))
                 L.call('mo_convt2x2_bwd_weight', du.data_ptr(), du_stride, C0, L.ptr(vin.t), vin.istride, ci,
                        L.ptr(vin.sc), L.ptr(vin.sh), 1 if vin.sc is not None else 0, gs, n, H, H, L.ptr(dWt), L.ptr(dbt),
-                       L.ptr(wsu), ls)
+                       L.ptr(wsu), dyf | (L.BF_IN0 * vin.bf), ls)
             lane.run(convt_wgrad, reads=[dcat, vin.t, vin.sc, vin.sh, dWt, dbt])
             da = _empty(n, ci, H, H, dev=dev)
-            L.call('mo_convt2x2_bwd_data', du.data_ptr(), du_stride, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H, st)
+            L.call('mo_convt2x2_bwd_data', du.data_ptr(), du_stride, C0, L.ptr(Wt), ci, n, H, H, L.ptr(da), ci * H * H,
+                   dyf, st)
         dz = fc_block_bwd(p, ctx.fc_sv, da.view(n, -1), grads, lane=lane)
         if state.get('adam_now') is not None and state.get('grad_out'):
             lane.run(lambda ls: state['adam_now'](('decoder.', 'expansion.'), ls))      # (eager Adam, see UnetEncodeFn.backward)

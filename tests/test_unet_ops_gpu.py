@@ -238,26 +238,48 @@ def test_convt2x2_fwd_bwd(L, n, gs, Ci, Co, H, W, act):
     scd, shd = (dev(sc), dev(sh)) if act else (None, None)
     out = torch.empty(n, Co, 2 * H, 2 * W, device='cuda')
     L.call('mo_convt2x2_fwd', L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd), 1 if act else 0, gs,
-           L.ptr(dev(Wt.detach())), L.ptr(dev(b.detach())), Co, n, H, W, L.ptr(out), Co * 4 * H * W, L.stream())
+           L.ptr(dev(Wt.detach())), L.ptr(dev(b.detach())), Co, n, H, W, L.ptr(out), Co * 4 * H * W, 0, L.stream())
     close(out, ref, what='convT fwd')
     dout = rand(25, tuple(ref.shape))
     ref.backward(dout)
     dd = dev(dout)
     din = torch.empty(n, Ci, H, W, device='cuda')
     L.call('mo_convt2x2_bwd_data', L.ptr(dd), Co * 4 * H * W, Co, L.ptr(dev(Wt.detach())), Ci, n, H, W, L.ptr(din),
-           Ci * H * W, L.stream())
+           Ci * H * W, 0, L.stream())
     close(din, a.grad, what='convT bwd data')
     dW = torch.empty(Ci, Co, 2, 2, device='cuda')
     db = torch.empty(Co, device='cuda')
     ws = torch.empty(max(lib.mo_unet_wgrad_ws_floats(Ci, 4 * Co, n * H * W), n * Co * 2), device='cuda')
     L.call('mo_convt2x2_bwd_weight', L.ptr(dd), Co * 4 * H * W, Co, L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd),
-           1 if act else 0, gs, n, H, W, L.ptr(dW), L.ptr(db), L.ptr(ws), L.stream())
+           1 if act else 0, gs, n, H, W, L.ptr(dW), L.ptr(db), L.ptr(ws), 0, L.stream())
     close(dW, Wt.grad, what='convT dW')
     close(db, b.grad, what='convT db')
+    db_ref = b.grad.clone()
+    # bf16 storage of the upsampled map and of the gradient w.r.t. it (the streaming kernels only): the same fp32
+    # arithmetic on the rounded tensors -- result rounded once, gradients exact in the bf16-rounded dout
+    if lib.mo_convt2x2_bf16_route(Ci, Co, n) and W % 4 == 0:
+        outb = torch.empty(n, Co, 2 * H, 2 * W, device='cuda', dtype=torch.bfloat16)
+        L.call('mo_convt2x2_fwd', L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd), 1 if act else 0, gs,
+               L.ptr(dev(Wt.detach())), L.ptr(dev(b.detach())), Co, n, H, W, L.ptr(outb), Co * 4 * H * W, L.BF_OUT, L.stream())
+        assert torch.equal(outb.cpu(), out.cpu().to(torch.bfloat16))
+        doutb = dout.to(torch.bfloat16)
+        x2 = x.detach().clone().requires_grad_(True)
+        a = act_view(x2, sc, sh, gs) if act else x2
+        a.retain_grad()
+        Wt.grad = None; b.grad = None
+        F.conv_transpose2d(a, Wt, b, stride=2).backward(doutb.float())
+        ddb = dev(doutb)
+        L.call('mo_convt2x2_bwd_data', L.ptr(ddb), Co * 4 * H * W, Co, L.ptr(dev(Wt.detach())), Ci, n, H, W, L.ptr(din),
+               Ci * H * W, L.BF_DY, L.stream())
+        close(din, a.grad, what='convT bwd data, bf16 dout')
+        L.call('mo_convt2x2_bwd_weight', L.ptr(ddb), Co * 4 * H * W, Co, L.ptr(xd), Ci * H * W, Ci, L.ptr(scd), L.ptr(shd),
+               1 if act else 0, gs, n, H, W, L.ptr(dW), L.ptr(db), L.ptr(ws), L.BF_DY, L.stream())
+        close(dW, Wt.grad, what='convT dW, bf16 dout')
+        close(db, b.grad, what='convT db, bf16 dout')
     db2 = torch.empty(Co, device='cuda')
     ws2 = torch.empty(n * Co * 2, device='cuda')
     L.call('mo_nchw_channel_sum', L.ptr(dd), Co * 4 * H * W, Co, n, 4 * H * W, L.ptr(db2), L.ptr(ws2), L.stream())
-    close(db2, b.grad, what='channel sum')
+    close(db2, db_ref, what='channel sum')
 
 
 @pytest.mark.parametrize('n,gs,Ci,Co,HW', [(4, 2, 4, 1, 256), (2, 1, 4, 3, 64), (6, 2, 4, 13, 64 * 64), (4, 2, 8, 8, 1028),
