@@ -119,6 +119,14 @@ int mo_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const float* vals,
 int mo_spmm_blk(const int32_t* rowptr, const int32_t* lcol, const float* vals, const int32_t* uptr,
                 const int32_t* usrc, int n_rows, int max_union, const void* X_bf16, void* Y, long J, int beta,
                 int y_bf16, void* stream);
+/* Y (+)= S1 X1 + S2 X2 in ONE pass over Y (both matrices blocked as for mo_spmm_blk over the same node numbering; sums in
+ * the order Y, S1's entries, S2's entries: bit-identical to the two mo_spmm_blk launches it replaces -- the backward of a
+ * layer accumulating the two static supports' hops into the gradient of the gated output, graph_wavenet.py:81-91). */
+int mo_spmm_blk2(const int32_t* rowptr1, const int32_t* lcol1, const float* vals1, const int32_t* uptr1,
+                 const int32_t* usrc1, int max_union1, const void* X1_bf16,
+                 const int32_t* rowptr2, const int32_t* lcol2, const float* vals2, const int32_t* uptr2,
+                 const int32_t* usrc2, int max_union2, const void* X2_bf16,
+                 int n_rows, void* Y, long J, int beta, int y_bf16, void* stream);
 /* dense support: Y[N][J] (+)= A_km^T @ X with A_km (N,N) row-major indexed [k][m]
  * (forward: A_km = adp; backward-data: A_km = adp^T). */
 int mo_adj_gemm(const float* A_km, int N, const float* X, float* Y, long J, int beta, void* stream);

@@ -47,6 +47,7 @@ SIGNATURES = {
     'mo_gemm_bf16_256': (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     'mo_skip_bwd_add': (i32, [vp, i32, i32, i64, i32, i32, vp, vp]),
     'mo_spmm_blk': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, i64, i32, i32, vp]),
+    'mo_spmm_blk2': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, vp]),
     'mo_skip_gather_bf16': (i32, [vp, vp, i32, i64, i32, vp, vp]),
     'mo_skip_wsplit': (i32, [vp, i32, i32, vp, vp]),
     'mo_wgrad_bf16_kk_ws_floats': (i64, [i32, i32, i64]),

@@ -1207,6 +1207,150 @@ extern "C" int mo_spmm_blk(const int32_t* rowptr, const int32_t* lcol, const flo
   return mo_launch_status();
 }
 
+// Two blocked products into ONE pass over Y:  Y (+)= S1 X1 + S2 X2  (the backward of a layer accumulates the two static
+// supports' hops into the fp32 gradient of the gated output: as two launches each read and wrote its 0.64 GB; the sums are
+// formed in the same order -- Y, then S1's entries, then S2's -- so the result is bit-identical to the two launches).
+// Per column chunk the union tile is staged twice (matrix 1, then 2) through the same LDS and the same prefetch registers.
+struct SbMat { const int* rowptr; const int* lcol; const float* vals; const int* uptr; const int* usrc; const unsigned short* X; };
+template <bool YBF>
+__global__ void __launch_bounds__(256) spmm_blk2_kernel(SbMat m0, SbMat m1, int n, int nb, void* __restrict__ Yv, long J,
+                                                        int nc, int nsplit, int beta) {
+  __shared__ uint4 tile[SB_UMAX * 32];
+  const long bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const long idx = bid >> 3;
+  const int blk = (int)(idx % nb);
+  const int split = (int)(idx / nb);
+  const int cstride = 8 * nsplit;
+  int chunk = xcd + 8 * split;
+  if (chunk >= nc) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l5 = lane & 31;
+  const int r0 = blk * SB_R + wave * 4;
+  int src[2][8], rp[2], eb[2], ee[2], myl0[2]; float myw0[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const SbMat& M = m ? m1 : m0;
+    const int u0 = M.uptr[blk], U = M.uptr[blk + 1] - u0;
+    rp[m] = M.rowptr[min(r0 + min(lane, 4), n)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int uu = wave * 2 + half + 8 * k;
+      src[m][k] = (uu < U) ? M.usrc[u0 + uu] : -1;
+    }
+    eb[m] = __builtin_amdgcn_readlane(rp[m], 0); ee[m] = __builtin_amdgcn_readlane(rp[m], 4);
+    myl0[m] = (eb[m] + lane < ee[m]) ? M.lcol[eb[m] + lane] : 0;
+    myw0[m] = (eb[m] + lane < ee[m]) ? M.vals[eb[m] + lane] : 0.f;
+  }
+  const uint2* t2 = reinterpret_cast<const uint2*>(tile);
+  uint4 v[8];
+  auto fetch = [&](const int m, const int c) {
+    const unsigned short* X = m ? m1.X : m0.X;
+    const long col8 = (long)c * 256 + 8 * l5;
+    const bool cv = col8 < J;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (src[m][k] >= 0 && cv) v[k] = *reinterpret_cast<const uint4*>(X + (long)src[m][k] * J + col8);
+    }
+  };
+  fetch(0, chunk);
+  for (; chunk < nc; chunk += cstride) {
+    const long col4 = (long)chunk * 256 + 4 * lane;
+    const bool ov = col4 < J;
+    float acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      __syncthreads();                                         // everybody is done with the previous tile
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int uu = wave * 2 + half + 8 * k;
+        if (src[m][k] >= 0) tile[uu * 32 + l5] = v[k];
+      }
+      __syncthreads();
+      if (m == 0) fetch(1, chunk);                             // in flight under this matrix's arithmetic
+      else if (chunk + cstride < nc) fetch(0, chunk + cstride);
+      if (r0 >= n) continue;
+      if (m == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+          const int r = r0 + q;
+          if (beta && r < n && ov) {
+            if (YBF) {
+              const uint2 o = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(Yv) + (long)r * J + col4);
+              acc[q][0] = sb_lo(o.x); acc[q][1] = sb_hi(o.x); acc[q][2] = sb_lo(o.y); acc[q][3] = sb_hi(o.y);
+            } else {
+              const float4 o = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Yv) + (long)r * J + col4);
+              acc[q][0] = o.x; acc[q][1] = o.y; acc[q][2] = o.z; acc[q][3] = o.w;
+            }
+          }
+        }
+      }
+      const SbMat& M = m ? m1 : m0;
+      for (int base = eb[m]; base < ee[m]; base += 64) {
+        int myl = myl0[m];
+        float myw = myw0[m];
+        if (base != eb[m]) {
+          const int e = base + lane;
+          myl = (e < ee[m]) ? M.lcol[e] : 0;
+          myw = (e < ee[m]) ? M.vals[e] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int q0 = max(__builtin_amdgcn_readlane(rp[m], q), base);
+          const int q1 = min(__builtin_amdgcn_readlane(rp[m], q + 1), base + 64);
+          for (int k = q0; k < q1; ++k) {
+            const int li = __builtin_amdgcn_readlane(myl, k - base);
+            const float w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(myw), k - base));
+            const uint2 t = t2[li * 64 + lane];
+            acc[q][0] += w * sb_lo(t.x); acc[q][1] += w * sb_hi(t.x);
+            acc[q][2] += w * sb_lo(t.y); acc[q][3] += w * sb_hi(t.y);
+          }
+        }
+      }
+    }
+    if (r0 >= n) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + q;
+      if (r < n && ov) {
+        if (YBF)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(Yv) + (long)r * J + col4) =
+              make_uint2(spmm_pack2(acc[q][0], acc[q][1]), spmm_pack2(acc[q][2], acc[q][3]));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Yv) + (long)r * J + col4) =
+              make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+      }
+    }
+  }
+}
+extern "C" int mo_spmm_blk2(const int32_t* rowptr1, const int32_t* lcol1, const float* vals1, const int32_t* uptr1,
+                            const int32_t* usrc1, int max_union1, const void* X1_bf16,
+                            const int32_t* rowptr2, const int32_t* lcol2, const float* vals2, const int32_t* uptr2,
+                            const int32_t* usrc2, int max_union2, const void* X2_bf16,
+                            int n_rows, void* Y, long J, int beta, int y_bf16, void* stream) {
+  MO_CHECK_ARG(rowptr1 && lcol1 && vals1 && uptr1 && usrc1 && X1_bf16 && rowptr2 && lcol2 && vals2 && uptr2 && usrc2 && X2_bf16);
+  MO_CHECK_ARG(Y && n_rows > 0 && J > 0 && (J % 8) == 0);
+  MO_CHECK_ARG(max_union1 >= 0 && max_union1 <= SB_UMAX && max_union2 >= 0 && max_union2 <= SB_UMAX);
+  MO_CHECK_ARG((((uintptr_t)X1_bf16) & 15) == 0 && (((uintptr_t)X2_bf16) & 15) == 0 && (((uintptr_t)Y) & 15) == 0);
+  const int nb = mo_cdiv(n_rows, SB_R);
+  const int nc = (int)((J + 255) / 256);
+  const int per_xcd = mo_cdiv(nc, 8);
+  int nsplit = (int)mo_cdiv(4096L, 8L * nb);
+  if (nsplit > per_xcd) nsplit = per_xcd;
+  if (nsplit < 1) nsplit = 1;
+  const long nblk = 8L * nb * nsplit;
+  MO_CHECK_ARG(nblk < (1L << 31));
+  SbMat a = {rowptr1, lcol1, vals1, uptr1, usrc1, (const unsigned short*)X1_bf16};
+  SbMat b = {rowptr2, lcol2, vals2, uptr2, usrc2, (const unsigned short*)X2_bf16};
+  dim3 grid((unsigned)nblk), block(256);
+  if (y_bf16) hipLaunchKernelGGL(spmm_blk2_kernel<true>, grid, block, 0, ST(stream), a, b, n_rows, nb, Y, J, nc, nsplit, beta);
+  else hipLaunchKernelGGL(spmm_blk2_kernel<false>, grid, block, 0, ST(stream), a, b, n_rows, nb, Y, J, nc, nsplit, beta);
+  return mo_launch_status();
+}
+
 // Small graphs (N <= 128: the 67-county Graph WaveNet inside Modified_UNET): the node-axis products are a few MFLOP, and
 // a 128x128 tile-engine launch spends ~30 us on one padded tile row.  Direct kernels instead:
 //   Y[m][j] (+)= sum_k A[k][m] * X[k][j]: one wave per output row and 256 columns, operands straight from L2;

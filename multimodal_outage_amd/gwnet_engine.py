@@ -35,6 +35,7 @@ def csr_from_dense(a):
 
 BLK_R, BLK_UMAX = 16, 64     # mo_spmm_blk: rows per block, largest neighbour union it stages (include/mo_hip.h)
 BLK_MIN_J = 16384            # below this row length the plain CSR kernel is as fast (measured, tools/bench_spmm.py)
+SPMM_DUAL = os.environ.get('MO_SPMM_DUAL', '1') != '0'    # A/B switch: two supports' accumulations into dg as one launch
 
 
 def cluster_order(patterns, R=BLK_R):
@@ -289,6 +290,19 @@ def _spmm(csr, n, X, Y, J, beta):
         return
     L.call('mo_spmm_csr', L.ptr(csr[0]), L.ptr(csr[1]), L.ptr(csr[2]), n, L.ptr(X), L.ptr(Y), J, beta,
            int(X.dtype == torch.bfloat16), int(Y.dtype == torch.bfloat16), L.stream())
+
+
+def _spmm2_ok(a, b, Y, J):
+    (ca, xa), (cb, xb) = a, b
+    return bool(SPMM_DUAL and ca[3] is not None and cb[3] is not None and xa.dtype == torch.bfloat16 and
+                xb.dtype == torch.bfloat16 and J >= BLK_MIN_J)
+
+
+def _spmm2(ca, xa, cb, xb, n, Y, J, beta):
+    ba, bb = ca[3], cb[3]
+    L.call('mo_spmm_blk2', L.ptr(ca[0]), L.ptr(ba[0]), L.ptr(ca[2]), L.ptr(ba[1]), L.ptr(ba[2]), ba[3], L.ptr(xa),
+           L.ptr(cb[0]), L.ptr(bb[0]), L.ptr(cb[2]), L.ptr(bb[1]), L.ptr(bb[2]), bb[3], L.ptr(xb),
+           n, L.ptr(Y), J, beta, int(Y.dtype == torch.bfloat16), L.stream())
 
 
 def _bf_mask(ts):
@@ -641,11 +655,20 @@ class GwnetFunction(torch.autograd.Function):
                             else:
                                 _dA(1 if dAdp_started else 0)
                             dAdp_started = True
+                    pend = []
                     for s in statics:
                         dx1s, dx2s = dsrcs[k], dsrcs[k + 1]
                         _spmm(s.bwd, N, dx2s, dx1s, J, 1)
-                        _spmm(s.bwd, N, dx1s, dg, J, 1)
+                        pend.append((s.bwd, dx1s))
                         k += 2
+                    # dg += S_a^T dx1_a + S_b^T dx1_b: the first hops of two supports in ONE pass over the fp32 dg
+                    # (mo_spmm_blk2; same order of sums as the two launches)
+                    while len(pend) >= 2 and _spmm2_ok(pend[0], pend[1], dg, J):
+                        (ca, xa), (cb, xb) = pend[0], pend[1]
+                        _spmm2(ca, xa, cb, xb, N, dg, J, 1)
+                        pend = pend[2:]
+                    for csr, x in pend:
+                        _spmm(csr, N, x, dg, J, 1)
                     if cfg.adaptive:
                         if side is not None:
                             torch.cuda.current_stream().wait_event(dx1_ready)

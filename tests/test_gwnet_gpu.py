@@ -476,7 +476,9 @@ def test_gwnet_blocked_route_at_full_size(c2_oracle, monkeypatch):
     calls.clear()
     y = m(xg)
     F.mse_loss(y, O['tgt'].cuda()).backward()
-    assert calls.count('mo_spmm_blk') == 32 + 28 and calls.count('mo_spmm_csr') == 0
+    # (backward: the two supports' final hops into dg of a layer are ONE mo_spmm_blk2 launch = two products)
+    assert calls.count('mo_spmm_blk') + 2 * calls.count('mo_spmm_blk2') == 32 + 28 and calls.count('mo_spmm_csr') == 0
+    assert calls.count('mo_spmm_blk2') == 7
     _c2_check(m, y, xg.grad, O, 2e-2, 1e-1, 'bf16 forced-blocked')
 
 

@@ -442,6 +442,46 @@ def test_spmm_blk_direct(L, kind, N, J, renumber):
             del ya, yb, y0
 
 
+@pytest.mark.parametrize('N,J', [(300, 16384), (3000, 24576), (67, 520)])
+def test_spmm_blk2_equals_two_launches(L, N, J):
+    """mo_spmm_blk2: Y (+)= S1 X1 + S2 X2 in one pass over Y -- the two static supports' hops into the fp32 gradient of a
+    layer's gated output (graph_wavenet.py:81-91 backwards).  Bit-identical to mo_spmm_blk(S1, X1) followed by
+    mo_spmm_blk(S2, X2, beta=1), for fp32 and bf16 Y, beta 0 and 1, two different graphs over one node numbering."""
+    from multimodal_outage_amd.gwnet_engine import csr_from_dense, block_unions, cluster_order
+    A1 = _blk_case('knn', N)
+    A2 = (A1.T * (1.0 + 0.5 * np.cos(np.arange(N * N).reshape(N, N)))).astype(np.float32)   # (the reverse graph, other weights)
+    order = cluster_order([A1])
+    mats = []
+    for A in (A1, A2):
+        A = A[np.ix_(order, order)]
+        rowptr, cols, vals = csr_from_dense(A)
+        lcol, uptr, usrc, umax = block_unions(rowptr, cols, N)
+        if umax > 64:
+            pytest.skip('union beyond the LDS staging')
+        mats.append([torch.from_numpy(a).cuda() for a in (rowptr, lcol, vals, uptr, usrc)] + [umax])
+    g = torch.Generator().manual_seed(5)
+    X1 = torch.randn(N, J, generator=g).to(torch.bfloat16).cuda()
+    X2 = torch.randn(N, J, generator=g).to(torch.bfloat16).cuda()
+    for ybf in (0, 1):
+        for beta in (0, 1):
+            y0 = torch.randn(N, J, generator=g)
+            y0 = (y0.to(torch.bfloat16) if ybf else y0).cuda()
+            ya, yb = y0.clone(), y0.clone()
+            (r1, l1, v1, u1, s1, m1), (r2, l2, v2, u2, s2, m2) = mats
+            L.call('mo_spmm_blk', L.ptr(r1), L.ptr(l1), L.ptr(v1), L.ptr(u1), L.ptr(s1), N, m1, L.ptr(X1), L.ptr(ya), J, beta,
+                   ybf, L.stream())
+            L.call('mo_spmm_blk', L.ptr(r2), L.ptr(l2), L.ptr(v2), L.ptr(u2), L.ptr(s2), N, m2, L.ptr(X2), L.ptr(ya), J, 1,
+                   ybf, L.stream())
+            L.call('mo_spmm_blk2', L.ptr(r1), L.ptr(l1), L.ptr(v1), L.ptr(u1), L.ptr(s1), m1, L.ptr(X1),
+                   L.ptr(r2), L.ptr(l2), L.ptr(v2), L.ptr(u2), L.ptr(s2), m2, L.ptr(X2), N, L.ptr(yb), J, beta, ybf, L.stream())
+            torch.cuda.synchronize()
+            if ybf:
+                # (two launches round the bf16 intermediate once more than the single pass)
+                close(yb.float(), ya.float(), tol=2.0 ** -7, what='spmm_blk2 bf16 result')
+            else:
+                assert torch.equal(ya, yb), (N, J, ybf, beta)
+
+
 def test_spmm_blk_rejects_bad_arguments(L):
     """Shapes the kernel's grid does not cover come back as MO_E* codes, not as launches."""
     lib = L.load()
