@@ -89,8 +89,8 @@ def alg_bytes(dtype):
 def unet_alg_bytes_fwd(cin, size, act_dtype):
     """SURVEY 8(d)'s per-op in+out accounting of the UNet conv stack for ONE tile, forward, at the element sizes the
     engine stores (unet_engine.bf_ok: raw conv outputs and pooled maps of <= 32 channels at >= 64x64 are bf16 in the bf16
-    mode; the network input, the ConvTranspose2d outputs, the second conv output of up1..3, everything below 64x64 and the
-    OutConv result are fp32).  All-fp32 it reproduces the survey's 29.7 MB for a 13x256x256 tile."""
+    mode, and so is the ConvTranspose2d output of up3 / up4; the network input, the other ConvTranspose2d outputs, the second
+    conv output of up1..3, everything below 64x64 and the OutConv result are fp32).  All-fp32 it reproduces the survey's 29.7 MB for a 13x256x256 tile."""
     from multimodal_outage_amd.unet_engine import bf_ok, ENC_CH, DEC_CH
     es = lambda co, s: 2 if bf_ok(act_dtype, co, s, s) else 4
     tot, s = 0, size
@@ -110,11 +110,13 @@ def unet_alg_bytes_fwd(cin, size, act_dtype):
     e_in = 4                                               # decoder fc output (fp32)
     for k, (ci, co) in enumerate(DEC_CH, 1):               # Up: ConvTranspose2d, DoubleConv over [skip, up]
         s2 = 2 * s
-        tot += ci * s * s * e_in + (ci // 2) * s2 * s2 * 4
+        # (the upsampled map is bf16 where the streaming ConvTranspose2d kernels write it: up3, up4 in the bf16 mode)
+        eu = 2 if (bf_ok(act_dtype, co, s2, s2) and ci <= 16 and ci // 2 <= 8) else 4
+        tot += ci * s * s * e_in + (ci // 2) * s2 * s2 * eu
         sk_c, _, sk_e = skips[4 - k]
         eb = es(co, s2)
         e2 = eb if k == 4 else 4
-        tot += conv(sk_c * s2 * s2 * sk_e + (ci // 2) * s2 * s2 * 4, co, s2, eb) + conv(co * s2 * s2 * eb, co, s2, e2)
+        tot += conv(sk_c * s2 * s2 * sk_e + (ci // 2) * s2 * s2 * eu, co, s2, eb) + conv(co * s2 * s2 * eb, co, s2, e2)
         s, e_in = s2, e2
     tot += 4 * s * s * e_in + cin * s * s * 4              # OutConv
     return float(tot)
@@ -503,7 +505,7 @@ def main():
     by_name = {}
     for name, e0, e1 in per_call:
         by_name[name] = by_name.get(name, 0.0) + e0.elapsed_time(e1) / n_serial
-    BLOCK = ('mo_tcn_fwd', 'mo_tcn_bwd', 'mo_tcn_pack_weights', 'mo_spmm_blk', 'mo_spmm_csr', 'mo_gcn_mlp_fwd',
+    BLOCK = ('mo_tcn_fwd', 'mo_tcn_bwd', 'mo_tcn_pack_weights', 'mo_spmm_blk', 'mo_spmm_blk2', 'mo_spmm_csr', 'mo_gcn_mlp_fwd',
              'mo_gcn_mlp_bwd', 'mo_bn_finalize', 'mo_bn_bwd')
     block_ms = sum(by_name.get(k, 0.0) for k in BLOCK)
     block_ms_in = sum(by_name_in.get(k, 0.0) for k in BLOCK)
