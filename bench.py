@@ -62,8 +62,9 @@ def alg_bytes(dtype):
     optimisation, start conv, head and the adaptive adjacency."""
     bf = dtype == 'bf16'
     e_h = 4                       # layer input x_in / pre-BN h / BN output: fp32 in both modes
-    e_gw = 4 + (2 if bf else 0)   # gated TCN output g: fp32 (+ the bf16 copy the node-axis products read)
-    e_gs = 2 if bf else 4         # g as the node-axis products read it
+    e_gw = 2 if bf else 4         # gated TCN output g as written: bf16 in the throughput mode (+ the fp32 crop rows of the
+                                  # skip path, counted with the skip conv below), fp32 otherwise
+    e_gs = 2 if bf else 4         # g as the node-axis products and the mlp read it
     e_x = 2 if bf else 4          # diffusion intermediates x1 / x2
     S_static, S = 2, 3
     touts, tins, t = [], [], 13
@@ -74,7 +75,7 @@ def alg_bytes(dtype):
         b = 32 * Tin * e_h                                   # TCN reads x_in
         b += 32 * To * e_gw                                  # writes g
         b += S_static * 32 * To * (e_gs + e_x)               # static hop 1: read g, write x1
-        b += 32 * To * (4 + 2 * S * e_x + e_h + e_h)         # mlp: g, (x1 direct + x1 gathered | x1, x2 adaptive), x_in crop; write h
+        b += 32 * To * (e_gs + 2 * S * e_x + e_h + e_h)      # mlp: g, (x1 direct + x1 gathered | x1, x2 adaptive), x_in crop; write h
         b += 32 * To * 2 * e_h                               # BatchNorm apply: read h, write x_out
         block += b
         step += b + 32 * To * (e_gs + 3 * e_x)               # adaptive hops: read g, write x1, read x1, write x2

@@ -30,7 +30,7 @@ const char* mo_strerror(int code);
 /* Bumped whenever an existing entry point changes its argument list (a stale libmo_hip.so called through a newer ctypes
  * table would silently misread its arguments): _lib.load() refuses a library whose mo_version() differs from
  * _lib.ABI_VERSION.  3 = round 3 (mo_nchw_to_nbtc/mo_nbtc_to_nchw node_new, UNet `dtypes` words, ...). */
-#define MO_ABI_VERSION 5
+#define MO_ABI_VERSION 6
 int mo_version(void);
 /* tuning switches for A/B measurements: "persist" (1: persistent skinny-K kernels; 0, default: one workgroup per tile) */
 int mo_set_option(const char* name, int value);
@@ -91,10 +91,14 @@ int mo_adp_bwd(const float* E1, const float* E2, const float* adp, float* dA, in
  *      the load; scale/shift may be null).  Weights are the reference tensors (32,32,1,K). --------- */
 int mo_tcn_pack_weights(const float* Wf, const float* Wg, int K, float* Wp, void* stream);
 int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
-               const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
+               const float* bf, const float* bg, int K, int dil, long G, int Tin,
+               float* g_out /* may be NULL when g_crop and g_bf16 are given */,
                void* g_bf16 /* optional bf16 copy of g_out, may be NULL */,
                int mfma_bf16 /* 1: contraction on the bf16 MFMA (operands rounded to bf16, fp32 accumulate:
-               the throughput mode); 0: exact fp32 MFMA */, void* stream);
+               the throughput mode); 0: exact fp32 MFMA */,
+               float* g_crop /* ABI 6, optional: fp32 g of the LAST crop_tf steps of every group only, compact
+               [G*crop_tf][32] -- all the skip path reads (graph_wavenet.py:230-236); the node-axis products and the
+               mlp read the bf16 copy, which is what they round g to anyway */, int crop_tf, void* stream);
 /* backward: recomputes the pre-activations; dpre (ws, G*Tout*64 floats) ; du[G*Tin][32] = conv^T(dpre)
  * (+ dres[(g,t-(Tin-Tout))] when dres != null: the residual path of graph_wavenet.py:247);
  * dWf,dWg (32,32,1,K), dbf,dbg (32). ws2: mo_wgrad_ws_floats(64, 32*K, G*Tout) floats. */
@@ -200,7 +204,8 @@ int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* const* dsrc
                    const float* W, long P, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
                    float* dW, float* db, float* ws, void* dlast_bf16 /* optional bf16 copy of dsrcs[ns-1] */,
                    int parts /* 1: data gradients, 2: weight/bias gradients, 3: both */,
-                   int src_bf16_mask /* as in mo_gcn_mlp_fwd */, int dsrc_bf16_mask /* same form: dsrcs[1..] are
+                   int src_bf16_mask /* as in mo_gcn_mlp_fwd (bit 0 allowed since ABI 6: source 0 read from
+                   its bf16 copy by the weight gradient) */, int dsrc_bf16_mask /* same form: dsrcs[1..] are
                    bf16 tensors */, void* stream);
 
 /* ---- loss + metrics (lit.py:33-38): sums[0..3] = {sum d^2, sum |d|, sum |d|/max(|y|,1.17e-6), n};

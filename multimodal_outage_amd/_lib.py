@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmo_hip.so')
 
 _lib = None
-ABI_VERSION = 5          # == MO_ABI_VERSION of include/mo_hip.h; bump both when an entry point's arguments change
+ABI_VERSION = 6          # == MO_ABI_VERSION of include/mo_hip.h; bump both when an entry point's arguments change
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
 
@@ -35,7 +35,7 @@ SIGNATURES = {
     'mo_adp_fwd': (i32, [vp, vp, i32, i32, vp, vp, vp]),
     'mo_adp_bwd': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp]),
     'mo_tcn_pack_weights': (i32, [vp, vp, i32, vp, vp]),
-    'mo_tcn_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, i32, vp]),
+    'mo_tcn_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, i32, vp, i32, vp]),
     'mo_tcn_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, vp,
                          vp, vp, i32, i32, vp]),
     'mo_spmm_csr': (i32, [vp, vp, vp, i32, vp, vp, i64, i32, i32, i32, vp]),

@@ -557,8 +557,9 @@ static bool rsw_ok(const MoOperand& A, const MoOperand& B, long P, int M, int N)
     if (!g.ptr || g.ld != 32 || g.drop_thresh) return false;
     if (g.To != B.seg[0].To || g.relu != B.seg[0].relu) return false;
     if (g.To < 0 || g.To >= 200) return false;
-    // bf16 storage: all of segments 1.. or none, segment 0 fp32, identity row map
-    if (g.bf16 != ((j > 0) ? B.seg[NB > 1 ? 1 : 0].bf16 : 0)) return false;
+    // bf16 storage: all of segments 1.. or none (segment 0: fp32, or its bf16 copy when the others are bf16), identity row map
+    if (j > 0 && g.bf16 != B.seg[1].bf16) return false;
+    if (j == 0 && g.bf16 && !(NB > 1 && B.seg[1].bf16)) return false;
     if (g.bf16 && g.To) return false;
   }
   return true;
@@ -572,7 +573,8 @@ static void rsw_launch2(const MoOperand& A, const MoOperand& B, float* slab, flo
   if (mf) {      // bf16 MFMA form (throughput mode): workgroups walk 128-row runs
     const bool bbf = NB > 1 && B.seg[1].bf16;
     dim3 g(nwg), b(256);
-    if (bbf) hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, false, true>), g, b, lds, st, A, B, slab, cs, P, post_b);
+    if (bbf && B.seg[0].bf16) hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, false, true, false, true>), g, b, lds, st, A, B, slab, cs, P, post_b);
+    else if (bbf) hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, false, true>), g, b, lds, st, A, B, slab, cs, P, post_b);
     else if (A.seg[0].bf16) hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, true, false, true>), g, b, lds, st, A, B, slab, cs, P, post_b);
     else hipLaunchKernelGGL((rs_wgrad_bf_kernel<MA, NB, true, false>), g, b, lds, st, A, B, slab, cs, P, post_b);
     return;
@@ -824,7 +826,8 @@ static void rs_tcn_launch(int which, int K, const RsTcnArgs& a, long rows, bool 
   if (nwg > cap) nwg = cap;
 #define RS_LAUNCH(KER) hipLaunchKernelGGL(KER, dim3((unsigned)nwg), dim3(256), 0, st, a)
 #define RS_CASE2(k, M) \
-    if (which == 0) RS_LAUNCH((rs_tcn_kernel<k, 0, M>)); else if (which == 1) RS_LAUNCH((rs_tcn_kernel<k, 1, M>)); \
+    if (which == 0 && a.crop) RS_LAUNCH((rs_tcn_kernel<k, 0, M, true>)); \
+    else if (which == 0) RS_LAUNCH((rs_tcn_kernel<k, 0, M>)); else if (which == 1) RS_LAUNCH((rs_tcn_kernel<k, 1, M>)); \
     else RS_LAUNCH((rs_tcn_du_kernel<k, M>));
 #define RS_CASE(k) if (K == k) { if (mf) { RS_CASE2(k, true) } else { RS_CASE2(k, false) } return; }
   RS_CASE(1) RS_CASE(2) RS_CASE(3)
@@ -835,19 +838,21 @@ static void rs_tcn_launch(int which, int K, const RsTcnArgs& a, long rows, bool 
 
 extern "C" int mo_tcn_fwd(const float* h_prev, const float* scale, const float* shift, const float* Wp,
                           const float* bf, const float* bg, int K, int dil, long G, int Tin, float* g_out,
-                          void* g_bf16, int mfma_bf16, void* stream) {
+                          void* g_bf16, int mfma_bf16, float* g_crop, int crop_tf, void* stream) {
   const int Tout = Tin - dil * (K - 1);
-  MO_CHECK_ARG(h_prev && Wp && bf && bg && g_out && K >= 1 && K <= MO_MAX_SEG && G > 0 && Tout > 0);
+  MO_CHECK_ARG(h_prev && Wp && bf && bg && (g_out || (g_crop && g_bf16)) && K >= 1 && K <= MO_MAX_SEG && G > 0 && Tout > 0);
   MO_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   MO_CHECK_ARG(G * Tin < (1L << 31));
+  MO_CHECK_ARG(!g_crop || (crop_tf >= 1 && crop_tf <= Tout && Tout < 65536 && G * (long)crop_tf * 128 < (1L << 32)));
   if (rs_tcn_ok(K, G, Tin, Tout) && rs_al16(h_prev) && rs_al16(g_out) && rs_al16(scale) && rs_al16(shift)) {
     RsTcnArgs a = {};
     a.h_prev = h_prev; a.scale = scale; a.shift = shift; a.Wp = Wp; a.bf = bf; a.bg = bg;
     a.out = g_out; a.out_bf = (unsigned short*)g_bf16; a.G = G; a.Tin = Tin; a.Tout = Tout; a.dil = dil;
+    a.crop = g_crop; a.crop_tf = g_crop ? crop_tf : 0;
     rs_tcn_launch(0, K, a, G * Tout, mfma_bf16 != 0, ST(stream));
     return mo_launch_status();
   }
-  if (mfma_bf16) return MO_EUNSUPPORTED;
+  if (mfma_bf16 || g_crop || !g_out) return MO_EUNSUPPORTED;
   MoOperand A, Bo; tcn_operands(h_prev, scale, shift, Wp, K, dil, G, Tin, Tout, A, Bo);
   MoEpi E; epi_init(E, g_out, 32);
   E.bias = bf; E.bias2 = bg; E.out_bf = (unsigned short*)g_bf16;
@@ -1446,7 +1451,8 @@ static void rs_mlp_launch(bool fwd, int ns, const RsMlpArgs& a, bool bf, hipStre
   const bool drop = a.drop_thresh != 0;
 #define RS_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)nwg), dim3(256), 0, st, a)
 #define RS_CASE2(k, B) \
-    if (fwd) { if (drop) RS_LAUNCH((rs_mlp_fwd_kernel<k, true, B>)); else RS_LAUNCH((rs_mlp_fwd_kernel<k, false, B>)); } \
+    if (fwd && B && a.s0bf) { if (drop) RS_LAUNCH((rs_mlp_fwd_kernel<k, true, B, B>)); else RS_LAUNCH((rs_mlp_fwd_kernel<k, false, B, B>)); } \
+    else if (fwd) { if (drop) RS_LAUNCH((rs_mlp_fwd_kernel<k, true, B>)); else RS_LAUNCH((rs_mlp_fwd_kernel<k, false, B>)); } \
     else { if (drop) RS_LAUNCH((rs_mlp_bwd_kernel<k, true, B>)); else RS_LAUNCH((rs_mlp_bwd_kernel<k, false, B>)); }
 #define RS_CASE(k) if (ns == k) { if (bf) { RS_CASE2(k, true) } else { RS_CASE2(k, false) } return; }
   RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
@@ -1455,7 +1461,8 @@ static void rs_mlp_launch(bool fwd, int ns, const RsMlpArgs& a, bool bf, hipStre
 #undef RS_CASE2
 }
 // bf16-storage masks of the mlp entry points: none, or every source but the first
-static bool rs_mask_ok(int mask, int ns) { return mask == 0 || (ns > 1 && mask == (((1 << ns) - 1) & ~1)); }
+// (forward / weight gradient: source 0 may be read from its bf16 copy as well -- every bit set)
+static bool rs_mask_ok(int mask, int ns) { return mask == 0 || (ns > 1 && (mask | 1) == ((1 << ns) - 1)); }
 
 extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, const float* b, long G, int Tout,
                               int Tin, const float* res, const float* rscale, const float* rshift,
@@ -1473,6 +1480,7 @@ extern "C" int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, 
     a.out[0] = h; a.W = W; a.bias = b; a.res = res; a.rscale = rscale; a.rshift = rshift; a.partial = partial;
     a.P = P; a.Tout = Tout; a.Tin = Tin;
     a.drop_seed = drop_seed; a.drop_thresh = drop_thresh; a.drop_scale = drop_scale;
+    a.s0bf = src_bf16_mask & 1;
     rs_mlp_launch(true, ns, a, src_bf16_mask != 0, ST(stream));
     return mo_launch_status();
   }
@@ -1659,7 +1667,7 @@ extern "C" int mo_gcn_mlp_bwd(const float* dh, const float* const* srcs, float* 
                               int dsrc_bf16_mask, void* stream) {
   MO_CHECK_ARG(dh && srcs && dsrcs && W && dW && db && ns >= 1 && ns <= MO_MAX_SEG && P > 0 && P < (1L << 31));
   MO_CHECK_ARG(ws || !(parts & 2));
-  MO_CHECK_ARG(rs_mask_ok(src_bf16_mask, ns) && rs_mask_ok(dsrc_bf16_mask, ns));
+  MO_CHECK_ARG(rs_mask_ok(src_bf16_mask, ns) && rs_mask_ok(dsrc_bf16_mask, ns) && !(dsrc_bf16_mask & 1));
   hipStream_t st = ST(stream);
   // data: dsrcs[s][p][c] = sum_co dm[p][co] W[co][s*32+c]
   MoOperand A = op_simple(dh, 32, P, 32);                 // XROWS rows = p, cols = k = co

@@ -222,6 +222,7 @@ struct RsMlpArgs {
   long P;
   int Tout, Tin;
   uint32_t drop_seed, drop_thresh; float drop_scale;
+  int s0bf;                       // fwd, bf16 sources: source 0 (the gated TCN output) is read from its bf16 copy too
 };
 
 // Bounds-checked stores through a buffer descriptor (num_records = the tensor's bytes): rows past P are
@@ -332,7 +333,8 @@ __device__ __forceinline__ void rs_get_b(const short* Xb, rs_v8s (&a)[2], int la
     a[h] = *reinterpret_cast<const rs_v8s*>(&Xb[(lane & 31) * RS_LDXB + 16 * h + 8 * (lane >> 5)]);
 }
 
-template <int NS, bool DROP, bool SBF>      // SBF: sources 1.. are stored as bf16 (source 0, the gated TCN output, fp32)
+template <int NS, bool DROP, bool SBF, bool S0BF = false>   // SBF: sources 1.. are stored as bf16 (source 0, the gated TCN
+                                                            // output, fp32 -- or, S0BF, read from its bf16 copy as well)
 __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
   // SBF also selects the bf16 MFMA: weights as bf16 [n][k] rows (stride KT+8), tiles as bf16
   __shared__ __attribute__((aligned(16))) float Ws[SBF ? 16 * (32 * NS + 8) : NS * 32 * RS_LDW];
@@ -362,8 +364,11 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
   const __amdgpu_buffer_rsrc_t hout = rs_rsrc(a.out[0], P * 128);
   const __amdgpu_buffer_rsrc_t resr = rs_rsrc(a.res, (P / To) * Ti * 128);
   __amdgpu_buffer_rsrc_t srcr[NS];
+  // (source 0 from its bf16 copy: the fp32 values would be rounded to bf16 by rs_put_f2b on the way into the MFMA -- the
+  //  same round-to-nearest-even that produced the copy -- so the product is bit-identical and 0.32 GB per layer stay home)
+  constexpr bool s0bf = SBF && S0BF;       // (a template parameter: as a run-time flag both paths cost 272 B of scratch)
 #pragma unroll
-  for (int s = 0; s < NS; ++s) srcr[s] = rs_rsrc(a.src[s], P * ((SBF && s > 0) ? 64 : 128));
+  for (int s = 0; s < NS; ++s) srcr[s] = rs_rsrc(a.src[s], P * ((SBF && (s > 0 || s0bf)) ? 64 : 128));
   const unsigned lane_off = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16);
   const unsigned lane_off_bf = (unsigned)((lane >> 2) * 64 + (lane & 3) * 16);
 
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
   float4 ring[RS_R][4];
   auto step_row0 = [&](long gi, int i) -> long { return gi * 128 + (i / NS) * 32; };   // i in [0, 4*NS)
   auto issue_step = [&](float4 (&dst)[4], long gi, int i) {
-    if (SBF && (i % NS) > 0) rs_issue_block_bf(dst, srcr[i % NS], step_row0(gi, i), lane_off_bf);
+    if (SBF && ((i % NS) > 0 || s0bf)) rs_issue_block_bf(dst, srcr[i % NS], step_row0(gi, i), lane_off_bf);
     else rs_issue_block(dst, srcr[i % NS], step_row0(gi, i), lane_off);
   };
 #pragma unroll
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void rs_mlp_fwd_kernel(RsMlpArgs a) {
       for (int s = 0; s < NS; ++s) {
         const int i = jb * NS + s;                 // step within the run
         const int slot = i % RS_R;
-        if (SBF) { if (s > 0) rs_put_b2b(Xb, ring[slot], lane); else rs_put_f2b(Xb, ring[slot], lane); }
+        if (SBF) { if (s > 0 || s0bf) rs_put_b2b(Xb, ring[slot], lane); else rs_put_f2b(Xb, ring[slot], lane); }
         else rs_put(X, ring[slot], lane);
         {
           const int in = i + RS_R;                 // the step this slot serves next
@@ -559,6 +564,7 @@ struct RsTcnArgs {
   unsigned short* out_bf;           // MODE 0: optional bf16 copy
   const float* dpre; const float* dres; float* du;   // data-gradient kernel
   long G; int Tin, Tout, dil;
+  float* crop; int crop_tf;         // MODE 0: fp32 g of the LAST crop_tf steps only, compact [G*crop_tf][32] (out may be null)
 };
 
 // byte offsets of the four 16-byte loads of a row-mapped 32x32 tile: output rows m0 + 8j + (lane>>3) of a
@@ -582,7 +588,8 @@ __device__ __forceinline__ void rs_issue_tile(float4 (&v)[4], __amdgpu_buffer_rs
   for (int j = 0; j < 4; ++j) v[j] = rs_load4(r, off[j]);
 }
 
-template <int K, int MODE, bool MF>     // MF: bf16 MFMA (throughput mode) instead of the exact fp32 MFMA
+template <int K, int MODE, bool MF, bool CROP = false>     // MF: bf16 MFMA (throughput mode) instead of the exact fp32 MFMA;
+                                                           // CROP (MODE 0): fp32 g of the last crop_tf steps only
 __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_kernel(RsTcnArgs a) {
   constexpr int LW = 65;
   constexpr int LWB = 32 * K + 8;                    // MF: bf16 [co' (64)][tau*32 + ci] rows
@@ -607,7 +614,8 @@ __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_ker
   if (w >= NG) return;
   const unsigned inv16 = 65536u / To + 1u;
   const __amdgpu_buffer_rsrc_t hr = rs_rsrc(a.h_prev, a.G * Ti * 128);
-  const __amdgpu_buffer_rsrc_t outr = rs_rsrc(a.out, P * (MODE == 0 ? 128 : (MF ? 128 : 256)));
+  const __amdgpu_buffer_rsrc_t outr = rs_rsrc(a.out, a.out ? P * (MODE == 0 ? 128 : (MF ? 128 : 256)) : 0);
+  const __amdgpu_buffer_rsrc_t cropr = rs_rsrc(a.crop, (MODE == 0 && CROP) ? a.G * a.crop_tf * 128 : 0);
   const __amdgpu_buffer_rsrc_t bfr = rs_rsrc(a.out_bf, (MODE == 0 && a.out_bf) ? P * 64 : 0);
   const __amdgpu_buffer_rsrc_t dgr = rs_rsrc(a.dg, MODE == 1 ? P * 128 : 0);
   const unsigned colb = (unsigned)((lane & 7) * 16);
@@ -634,6 +642,7 @@ __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_ker
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
       const long m0 = gi * 128 + jb * 32;
+      const unsigned cum0 = (unsigned)(m0 < P ? m0 : 0), cg0 = CROP ? cum0 / To : 0, ct0 = cum0 - cg0 * To;   // (crop store)
       float dgv[16];
       if (MODE == 1) {
 #pragma unroll
@@ -690,9 +699,23 @@ __global__ __launch_bounds__(256, (K <= 2 && MODE == 0) ? 3 : 2) void rs_tcn_ker
         const float f0 = mo_tanh(accf[r] + bfv), f1 = mo_tanh(accf[r + 1] + bfv);
         const float g0 = mo_sigmoid(accg[r] + bgv), g1 = mo_sigmoid(accg[r + 1] + bgv);
         if (MODE == 0) {
-          rs_store_f32(outr, m * 32 + n, f0 * g0);
-          rs_store_f32(outr, (m + 1) * 32 + n, f1 * g1);
+          if (!CROP) {
+            rs_store_f32(outr, m * 32 + n, f0 * g0);
+            rs_store_f32(outr, (m + 1) * 32 + n, f1 * g1);
+          }
           rs_store_bf16_pair(bfr, m * 32, n, f0 * g0, f1 * g1);
+          if (CROP) {
+            // the skip path reads the last crop_tf steps of every (node, window) group in fp32: only those rows
+            // ((group, step) of a row by the block's one division + the reciprocal, as rs_tile_offsets does)
+            const unsigned o = (unsigned)((r & 3) + 8 * (r >> 2) + 4 * half);
+            const unsigned x0 = ct0 + o, q0 = (x0 * inv16) >> 16, tt0 = x0 - q0 * To;
+            const unsigned x1 = x0 + 1, q1 = (x1 * inv16) >> 16, tt1 = x1 - q1 * To;
+            const unsigned tc = To - (unsigned)a.crop_tf;
+            const long c0 = (m < P && tt0 >= tc) ? ((long)(cg0 + q0) * a.crop_tf + (tt0 - tc)) * 32 + n : 0x3FFFFFFFL;
+            const long c1 = (m + 1 < P && tt1 >= tc) ? ((long)(cg0 + q1) * a.crop_tf + (tt1 - tc)) * 32 + n : 0x3FFFFFFFL;
+            rs_store_f32(cropr, c0, f0 * g0);                           // (0x3FFFFFFF * 4: outside every descriptor)
+            rs_store_f32(cropr, c1, f1 * g1);
+          }
         } else if (MF) {        // throughput mode: the pre-activation gradients are a bf16 [P][64] tensor
           rs_store_bf16_pair(outr, m * 64, n, dgv[r] * g0 * (1.f - f0 * f0), dgv[r + 1] * g1 * (1.f - f1 * f1), 64);
           rs_store_bf16_pair(outr, m * 64 + 32, n, dgv[r] * f0 * g0 * (1.f - g0), dgv[r + 1] * f1 * g1 * (1.f - g1), 64);
@@ -842,7 +865,8 @@ __device__ __forceinline__ void rs_get_tr(const short* Xb, rs_v8s (&f)[2], int l
   }
 }
 
-template <int MA, int NB, bool MAPPED, bool BBF, bool ABF = false>    // ABF: a is stored as bf16 (the TCN's dpre)
+template <int MA, int NB, bool MAPPED, bool BBF, bool ABF = false, bool B0BF = false>    // ABF: a is stored as bf16 (the
+                                                          // TCN's dpre); B0BF: segment 0 of b from its bf16 copy too
 __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOperand B, float* __restrict__ slab,
                                                             float* __restrict__ cs, long P, int post_b) {
   extern __shared__ float rs_sm[];
@@ -872,13 +896,14 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
 
   const unsigned To = MAPPED ? (unsigned)B.seg[0].To : 1u;
   const unsigned inv16 = 65536u / To + 1u;
+  constexpr bool b0bf = BBF && !MAPPED && B0BF;        // segment 0 from its bf16 copy too (bit-identical: see rs_mlp_fwd_kernel)
   const __amdgpu_buffer_rsrc_t ar = rs_rsrc(A.seg[0].ptr, P * LDA * (ABF ? 2 : 4));
   __amdgpu_buffer_rsrc_t br[NB];
   float4 bsc[NB], bsh[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const long rows = MAPPED ? (P / To) * B.seg[j].Ti : P;
-    br[j] = rs_rsrc(B.seg[j].ptr, rows * ((BBF && j > 0) ? 64 : 128));
+    br[j] = rs_rsrc(B.seg[j].ptr, rows * ((BBF && (j > 0 || b0bf)) ? 64 : 128));
     bsc[j] = make_float4(1.f, 1.f, 1.f, 1.f); bsh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (B.seg[j].scale) {
       bsc[j] = *reinterpret_cast<const float4*>(B.seg[j].scale + 4 * (lane & 7));
@@ -912,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
         rs_tile_offsets(off, row0, P, To, (unsigned)B.seg[j].Ti, inv16, B.seg[j].off, 128u,
                         (unsigned)((lane & 7) * 16), lane);
         rs_issue_tile(dst, br[j], off);
-      } else if (BBF && j > 0) {
+      } else if (BBF && (j > 0 || b0bf)) {
         rs_issue_block_bf(dst, br[j], row0, lane_off_bf);
       } else {
         rs_issue_block(dst, br[j], row0, lane_off);
@@ -983,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_bf_kernel(MoOperand A, MoOper
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int i = jb * S + MA + j, slot = i % RS_R;
-          if (BBF && j > 0) {
+          if (BBF && (j > 0 || b0bf)) {
             rs_put_b2b(Xb, ring[slot], lane);
           } else {
             if (post_b) {

@@ -36,6 +36,7 @@ def csr_from_dense(a):
 BLK_R, BLK_UMAX = 16, 64     # mo_spmm_blk: rows per block, largest neighbour union it stages (include/mo_hip.h)
 BLK_MIN_J = 16384            # below this row length the plain CSR kernel is as fast (measured, tools/bench_spmm.py)
 SPMM_DUAL = os.environ.get('MO_SPMM_DUAL', '1') != '0'    # A/B switch: two supports' accumulations into dg as one launch
+G_BF_ONLY = os.environ.get('MO_G_BF_ONLY', '1') != '0'    # A/B switch: throughput mode keeps g as bf16 + the skip crop in fp32
 
 
 def cluster_order(patterns, R=BLK_R):
@@ -365,12 +366,24 @@ class GwnetFunction(torch.autograd.Function):
             Wp = torch.empty(K * 64 * 32, device=dev, dtype=torch.float32)
             L.call('mo_tcn_pack_weights', L.ptr(p[f'filter_convs.{i}.weight']),
                    L.ptr(p[f'gate_convs.{i}.weight']), K, L.ptr(Wp), st)
-            g = _e(P, 32, dev)
             g_bf = torch.empty((P, 32), device=dev, dtype=torch.bfloat16) if use_bf else None
-            L.call('mo_tcn_fwd', L.ptr(h), L.ptr(scale), L.ptr(shift), L.ptr(Wp),
-                   L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, d, G, Tin,
-                   L.ptr(g), L.ptr(g_bf), int(use_bf), st)
-            srcs = [g]
+            if use_bf and G_BF_ONLY:
+                # throughput mode: g exists as its bf16 copy -- what the node-axis products, the mlp and its weight gradient
+                # round it to anyway (bit-identical results) -- plus the fp32 values of the last Tf steps, all the skip
+                # path reads: the full fp32 tensor (0.64 GB per layer written, read twice) is gone
+                g = _e(G * Tf, 32, dev)
+                L.call('mo_tcn_fwd', L.ptr(h), L.ptr(scale), L.ptr(shift), L.ptr(Wp),
+                       L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, d, G, Tin,
+                       None, L.ptr(g_bf), 1, L.ptr(g), Tf, st)
+                g_T = Tf
+                srcs = [g_bf]
+            else:
+                g = _e(P, 32, dev)
+                L.call('mo_tcn_fwd', L.ptr(h), L.ptr(scale), L.ptr(shift), L.ptr(Wp),
+                       L.ptr(p[f'filter_convs.{i}.bias']), L.ptr(p[f'gate_convs.{i}.bias']), K, d, G, Tin,
+                       L.ptr(g), L.ptr(g_bf), int(use_bf), None, 0, st)
+                g_T = Tout
+                srcs = [g]
             bf_saved = None
             if cfg.gcn:
                 # the dense (adaptive, MFMA-bound) branch runs on a side HIP stream beside the sparse
@@ -421,7 +434,7 @@ class GwnetFunction(torch.autograd.Function):
             L.call('mo_bn_finalize', L.ptr(partial), nblk, P, L.ptr(p[f'bn.{i}.weight']),
                    L.ptr(p[f'bn.{i}.bias']), L.ptr(rm), L.ptr(rv), 0.1, 1e-5, 1 if training else 0,
                    L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), st)
-            layers.append(dict(h_in=h, scale=scale, shift=shift, Wp=Wp, g=g, srcs=srcs, h=hn, bf=bf_saved,
+            layers.append(dict(h_in=h, scale=scale, shift=shift, Wp=Wp, g=g, g_T=g_T, srcs=srcs, h=hn, bf=bf_saved,
                                stats=stats, Tin=Tin, Tout=Tout, seed=seed, thresh=lt, dscale=ls))
             h, scale, shift, Tin = hn, stats[0], stats[1], Tout
 
@@ -436,7 +449,7 @@ class GwnetFunction(torch.autograd.Function):
         for c0 in range(0, cfg.L, 8):
             ids = list(range(c0, min(cfg.L, c0 + 8)))
             bsum = torch.stack([p[f'skip_convs.{i}.bias'] for i in ids]).sum(0)
-            touts = (_C.c_int * len(ids))(*[layers[i]['Tout'] for i in ids])
+            touts = (_C.c_int * len(ids))(*[layers[i]['g_T'] for i in ids])      # (steps per group of the stored fp32 g)
             L.call('mo_skip_fwd', L.ptr_array([layers[i]['g'] for i in ids]), touts,
                    L.ptr_array([p[f'skip_convs.{i}.weight'] for i in ids]), len(ids), L.ptr(bsum), cfg.Cs, G, Tf,
                    L.ptr(skip), 1 if c0 > 0 else 0, int(head_bf), L.ptr(skip_bf), st)
@@ -551,7 +564,7 @@ class GwnetFunction(torch.autograd.Function):
 
                     def _skip_w(dskip_bf=dskip_bf, gWs_all=gWs_all):
                         gcat = torch.empty((P_f, 32 * cfg.L), device=dev, dtype=torch.bfloat16)
-                        touts = (_C.c_int * cfg.L)(*[ctx.layers[i]['Tout'] for i in range(cfg.L)])
+                        touts = (_C.c_int * cfg.L)(*[ctx.layers[i]['g_T'] for i in range(cfg.L)])
                         L.call('mo_skip_gather_bf16', L.ptr_array([ctx.layers[i]['g'] for i in range(cfg.L)]), touts, cfg.L,
                                G, Tf, L.ptr(gcat), L.stream())
                         dW_all = _e(cfg.Cs, 32 * cfg.L, dev)
@@ -594,8 +607,11 @@ class GwnetFunction(torch.autograd.Function):
                        L.ptr(wsb), st)
                 grads[f'bn.{i}.weight'], grads[f'bn.{i}.bias'] = gg, gb
                 # mlp / residual-conv backward (graph_wavenet.py:95-97 / :245)
-                dsrcs = [torch.empty((P, 32), device=dev, dtype=sr.dtype) for sr in srcs]
+                # (the gradient of source 0, the gated output, is the fp32 accumulator dg even where g itself is read as bf16)
+                dsrcs = [torch.empty((P, 32), device=dev, dtype=torch.float32 if k_ == 0 else sr.dtype)
+                         for k_, sr in enumerate(srcs)]
                 smask = _bf_mask(srcs)
+                dmask = smask & ~1
                 if cfg.gcn:
                     W = p[f'gconv.{i}.mlp.mlp.weight']
                     kW, kb = f'gconv.{i}.mlp.mlp.weight', f'gconv.{i}.mlp.mlp.bias'
@@ -604,13 +620,13 @@ class GwnetFunction(torch.autograd.Function):
                     kW, kb = f'residual_convs.{i}.weight', f'residual_convs.{i}.bias'
                 gW = gbuf(kW, W); gbm = gbuf(kb, shape=(32,))
                 L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
-                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), None, None, 1, smask, smask,
+                       ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm), None, None, 1, smask, dmask,
                        st)
 
-                def _mlp_w(dh=dh, srcs=srcs, dsrcs=dsrcs, ns=ns, W=W, P=P, ly=ly, gW=gW, gbm=gbm, smask=smask):
+                def _mlp_w(dh=dh, srcs=srcs, dsrcs=dsrcs, ns=ns, W=W, P=P, ly=ly, gW=gW, gbm=gbm, smask=smask, dmask=dmask):
                     L.call('mo_gcn_mlp_bwd', L.ptr(dh), L.ptr_array(srcs), L.ptr_array(dsrcs), ns, L.ptr(W), P,
                            ly['seed'], ly['thresh'], ly['dscale'], L.ptr(gW), L.ptr(gbm),
-                           L.ptr(ws_for(32, 32 * ns, P)), None, 2, smask, smask, L.stream())
+                           L.ptr(ws_for(32, 32 * ns, P)), None, 2, smask, dmask, L.stream())
                 lane.run(_mlp_w, reads=(dh,))
                 grads[kW], grads[kb] = gW, gbm
                 dg = dsrcs[0]
@@ -692,7 +708,7 @@ class GwnetFunction(torch.autograd.Function):
                 gWs = gWs_all[i]
             else:
                 gWs = gbuf(f'skip_convs.{i}.weight', Ws)
-                lane.run(lambda g=g, gWs=gWs, Tout=Tout: L.call(
+                lane.run(lambda g=g, gWs=gWs, Tout=ly['g_T']: L.call(
                     'mo_conv1x1_bwd_weight', L.ptr(dskip), cfg.Cs, P_f, L.ptr(g), 32, Tf, Tout, Tout - Tf, 0,
                     L.ptr(gWs), None, L.ptr(ws_for(cfg.Cs, 32, P_f)), L.stream()), reads=(dskip,))
             grads[f'skip_convs.{i}.weight'] = gWs

@@ -214,9 +214,17 @@ def test_tcn_fwd_bwd(L, B, N, Tin, K, dil, affine, mf):
     g_bf = torch.empty(G * Tout, 32, device='cuda', dtype=torch.bfloat16)
     scd, shd = (dev(sc), dev(sh)) if affine else (None, None)
     L.call('mo_tcn_fwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
-           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(g), L.ptr(g_bf), mf, L.stream())
+           L.ptr(dev(bg.detach())), K, dil, G, Tin, L.ptr(g), L.ptr(g_bf), mf, None, 0, L.stream())
     close(g, nbtc(g_ref), tol, what='g')
     assert torch.equal(g_bf.cpu(), g.cpu().to(torch.bfloat16))          # fused bf16 copy == RNE of the fp32 result
+    # ABI 6: no full fp32 g, only the last Tf steps of every group (what the skip path reads) in a compact buffer
+    for Tf in sorted({1, min(2, Tout), Tout}):
+        crop = torch.full((G * Tf, 32), float('nan'), device='cuda')
+        g_bf2 = torch.empty_like(g_bf)
+        L.call('mo_tcn_fwd', L.ptr(hp), L.ptr(scd), L.ptr(shd), L.ptr(Wp), L.ptr(dev(bf.detach())),
+               L.ptr(dev(bg.detach())), K, dil, G, Tin, None, L.ptr(g_bf2), mf, L.ptr(crop), Tf, L.stream())
+        assert torch.equal(g_bf2, g_bf)
+        assert torch.equal(crop.view(G, Tf, 32), g.view(G, Tout, 32)[:, Tout - Tf:, :])
 
     dg = rand(27, tuple(g_ref.shape))
     dres = rand(28, tuple(g_ref.shape))        # residual-path gradient, cropped add (graph_wavenet.py:247)

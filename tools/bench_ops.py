@@ -116,7 +116,7 @@ if want('tcn'):
     g = torch.empty(P, 32, device=dev)
     gbf = torch.empty(P, 32, device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: L.call('mo_tcn_fwd', L.ptr(res), L.ptr(sc), L.ptr(sh), L.ptr(Wp), L.ptr(b), L.ptr(b), K, d, G,
-                               Tin, L.ptr(g), L.ptr(gbf), MF, st))
+                               Tin, L.ptr(g), L.ptr(gbf), MF, None, 0, st))
     report('tcn_fwd (h -> g, g_bf16)', ms, int(row * (Tin / Tout + 1.5)))
     du = torch.empty(G * Tin, 32, device=dev)
     dpre = torch.empty(P * 64, device=dev)
