@@ -676,6 +676,29 @@ def test_gcn_mlp_bf16_storage(L, B, N, Tin, Tout, ns, drop):
         close(dsrcs[s_].float(), dcat[:, 32 * s_:32 * (s_ + 1)], 8e-3, what=f'dsrc{s_} (bf16)')
     close(dW, dm.t() @ cat, 1e-2, what='dWm (bf16 sources, bf16 MFMA)')
     close(db, dm.sum(0), what='dbm')
+    # ABI 6: source 0 read from its bf16 copy as well (every mask bit set).  The kernels round the fp32 source 0 to bf16
+    # on the way into the MFMA, so with a source 0 that is exactly representable in bf16 both forms are bit-identical --
+    # which is how the engine uses it (the copy IS the rounding of g)
+    s0 = srcs[0].to(torch.bfloat16)
+    sd_f = [dev(s0.float())] + sd[1:]
+    sd_b = [dev(s0)] + sd[1:]
+    full = (1 << ns) - 1
+    h_f = torch.empty(P, 32, device='cuda'); h_b = torch.empty(P, 32, device='cuda')
+    p_f = torch.empty_like(partial); p_b = torch.empty_like(partial)
+    for sdx, hx, px, mk in ((sd_f, h_f, p_f, mask), (sd_b, h_b, p_b, full)):
+        L.call('mo_gcn_mlp_fwd', L.ptr_array(sdx), ns, L.ptr(dev(W)), L.ptr(dev(b)), G, Tout, Tin, L.ptr(dev(res)),
+               None, None, seed, thresh, dscale, L.ptr(hx), L.ptr(px), mk, L.stream())
+    nw = ((P + 127) // 128) * 64                        # (the BatchNorm partial sums the kernel writes)
+    assert torch.equal(h_f, h_b) and torch.equal(p_f[:nw], p_b[:nw])
+    dW_f = torch.empty_like(dW); dW_b = torch.empty_like(dW); db_f = torch.empty_like(db); db_b = torch.empty_like(db)
+    for sdx, dWx, dbx, mk in ((sd_f, dW_f, db_f, mask), (sd_b, dW_b, db_b, full)):
+        L.call('mo_gcn_mlp_bwd', L.ptr(dev(dhh)), L.ptr_array(sdx), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P,
+               seed, thresh, dscale, L.ptr(dWx), L.ptr(dbx), L.ptr(wsm), None, 2, mk, mask, L.stream())
+    assert torch.equal(dW_f, dW_b) and torch.equal(db_f, db_b)
+    # (the gradient of source 0 stays an fp32 tensor: bit 0 of the gradient mask is refused)
+    assert lib.mo_gcn_mlp_bwd(L.ptr(dev(dhh)), L.ptr_array(sd_b), L.ptr_array(dsrcs), ns, L.ptr(dev(W)), P, seed, thresh,
+                              dscale, L.ptr(dW_b), L.ptr(db_b), L.ptr(wsm), None, 1, full, full, L.stream()) != 0
+
 
 def test_metrics_and_grad(L):
     lib = L.load()
