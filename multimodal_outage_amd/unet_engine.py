@@ -17,6 +17,7 @@ WGRAD_LANE = os.environ.get('MO_UNET_WGRAD_LANE', '1') != '0'     # A/B switch: 
 # experiments on where the bf16 mode's deep-stage gradient error comes from (tests: modified_unet_H7 by stage)
 GRAD_F32 = os.environ.get('MO_UNET_GRAD_F32', '0') != '0'         # gradient tensors (dy, da, dx) stored fp32 in the bf16 mode
 DGRAD_F32 = os.environ.get('MO_UNET_DGRAD_F32', '0') != '0'       # data gradients on the exact-fp32 kernels in the bf16 mode
+U_BF = os.environ.get('MO_UNET_U_BF', '1') != '0'                 # A/B switch: upsampled maps (and the concat gradient) of up3 / up4 as bf16
 
 
 class _Lane:
@@ -485,7 +486,7 @@ class UnetDecodeFn(torch.autograd.Function):
             # MFMA anyway, so the forward result is bit-identical; per window this takes 0.37 GB (u: one write, two reads)
             # and 0.6 GB (the gradient: written by the concat conv's data gradient, read by the skip side's activation
             # backward and by ConvTranspose2d's two gradients) off the step's 18 GB.
-            ubf = bool(bf_ok(state.get('act_dtype', 'f32'), co, 2 * H, 2 * H) and not GRAD_F32 and
+            ubf = bool(U_BF and bf_ok(state.get('act_dtype', 'f32'), co, 2 * H, 2 * H) and not GRAD_F32 and
                        L.load().mo_convt2x2_bf16_route(ci, ci // 2, n))
             u = _empty(n, ci // 2, 2 * H, 2 * H, dev=dev, bf=ubf)
             L.call('mo_convt2x2_fwd', L.ptr(v.t), v.istride, ci, L.ptr(v.sc), L.ptr(v.sh), 1 if v.sc is not None else 0,

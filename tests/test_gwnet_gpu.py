@@ -482,6 +482,35 @@ def test_gwnet_blocked_route_at_full_size(c2_oracle, monkeypatch):
     _c2_check(m, y, xg.grad, O, 2e-2, 1e-1, 'bf16 forced-blocked')
 
 
+def test_throughput_mode_byte_savings_are_bit_identical(c2_oracle, monkeypatch):
+    """Round 3's two byte savings in the throughput mode change no bit of the step: (a) the gated output stored as bf16 plus
+    the fp32 rows of the skip crop instead of a full fp32 tensor (mlp forward / weight gradient and the node-axis products
+    round it to bf16 anyway), (b) the two static supports' hops into dg as one mo_spmm_blk2 launch (same order of sums).
+    Config 2 at N=3000, train mode with dropout (same seed): output, input gradient and every parameter gradient equal."""
+    from multimodal_outage_amd import gwnet_engine as E
+    O = c2_oracle
+    monkeypatch.setattr(E, 'BLK_MIN_J', 0)                 # (B = 2: force the blocked SpMM so that (b) is exercised)
+    res = {}
+    for g_bf_only, dual in ((True, True), (False, False)):
+        monkeypatch.setattr(E, 'G_BF_ONLY', g_bf_only)
+        monkeypatch.setattr(E, 'SPMM_DUAL', dual)
+        torch.manual_seed(77)
+        m = _model(C2, O['sup'], dropout=0.3).train()
+        m.dense_dtype = 'bf16'
+        xg = O['x'].cuda().requires_grad_(True)
+        torch.manual_seed(78)                               # (the dropout seeds of the layers are drawn from torch's RNG)
+        y = m(xg)
+        F.mse_loss(y, O['tgt'].cuda()).backward()
+        res[g_bf_only] = (y.detach().clone(), xg.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
+                                                                if p.grad is not None})
+    ya, ga, pa = res[True]
+    yb, gb, pb = res[False]
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    assert pa.keys() == pb.keys() and len(pa) > 40
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+
+
 def test_gwnet_bench_shape_b256_replicated_windows(c2_oracle):
     """The benchmark's own shape: (256, 32, 3000, 12), throughput mode, dropout 0 -- 1.18 GB tensors, byte offsets
     beyond 2^30, 9.2 M-row runs, the ring GEMM and mo_spmm_blk at J = 98304 inside the engine.  The batch is the
