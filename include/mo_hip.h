@@ -187,7 +187,8 @@ long mo_mlp_partial_floats(long P);
 int mo_gcn_mlp_fwd(const float* const* srcs, int ns, const float* W, const float* b, long G, int Tout,
                    int Tin, const float* res, const float* rscale, const float* rshift,
                    uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* h,
-                   float* partial, int src_bf16_mask /* 0, or every bit but bit 0: srcs[1..] are stored as bf16 */,
+                   float* partial, int src_bf16_mask /* 0, or bits 1..ns-1: srcs[1..] are stored as bf16; bit 0 too (ABI 6): srcs[0], the
+                   gated output, is read from its bf16 copy as well -- the kernel rounds it to bf16 either way */,
                    void* stream);
 /* BatchNorm2d finalize (training: batch stats + running-stat update, momentum 0.1 semantics of
  * nn.BatchNorm2d; eval: running stats).  Outputs scale/shift (the folded affine), mean, rstd. */
