@@ -501,18 +501,39 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
     // the 18 k-steps of a chunk: the tile / weight offsets of this lane's k = 4 i + lk do not depend on the chunk -- formed once
     // per kernel (kstep_b / kstep_w), not by two integer divisions per step (the counters showed 7.3 VALU instructions per
     // MFMA in this loop)
+    if constexpr (MB == 4 && TW == 32) {                          // (64 output channels at 32 x 32: the unrolled form measured
+                                                                 //  102 us against 90 us for the rolled loop)
+      for (int ks = 0; ks < nk; ks += 4) {
+        const int k = ks + lk;
+        const bool ok = k < nk;
+        const int kk = ok ? k : 0;
+        const int c = kk / 9, tap = kk - 9 * c, ky = tap / 3, kx = tap - 3 * ky;
+        const int boff = c * PS + ky * LDT + kx;
+        const float m = ok ? 1.f : 0.f;
+        float af[MB];
 #pragma unroll
-    for (int i = 0; i < UX_CIC * 9 / 4; ++i) {
-      if (4 * i >= nk) break;                                    // (a last chunk of fewer than 8 channels)
-      const float m = (4 * i + lk < nk) ? 1.f : 0.f;
-      float af[MB];
+        for (int mb = 0; mb < MB; ++mb) af[mb] = wsm[kk * CP + mb * 16 + lj] * m;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) af[mb] = wsm[kstep_w[i] + mb * 16] * m;
+        for (int nb = 0; nb < 4; ++nb) {
+          const float bv = xs[boff + poff[nb]];
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        const float bv = xs[kstep_b[i] + poff[nb]];
+          for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bv, acc[mb][nb], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bv, acc[mb][nb], 0, 0, 0);
+      for (int i = 0; i < UX_CIC * 9 / 4; ++i) {
+        if (4 * i >= nk) break;                                  // (a last chunk of fewer than 8 channels)
+        const float m = (4 * i + lk < nk) ? 1.f : 0.f;
+        float af[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) af[mb] = wsm[kstep_w[i] + mb * 16] * m;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const float bv = xs[kstep_b[i] + poff[nb]];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bv, acc[mb][nb], 0, 0, 0);
+        }
       }
     }
   }
