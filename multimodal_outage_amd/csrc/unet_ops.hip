@@ -1021,12 +1021,69 @@ __global__ void unet_act_kernel(const float* __restrict__ y, long istride, int C
   if (bfo) { __bf16 tb = (__bf16)v; reinterpret_cast<unsigned short*>(out)[o] = __builtin_bit_cast(unsigned short, tb); }
   else out[o] = v;
 }
+// the same on a planar grid (x: 4-output pieces of a plane, y: channel, z: image), 4 outputs per thread from 16-byte
+// loads: the one-element kernel above spends seven 64-bit divisions and four scalar loads per output (1.9 TB/s on the
+// 256^2 pool)
+template <bool POOL>
+__global__ __launch_bounds__(256) void unet_act4_kernel(const float* __restrict__ y, long istride, int C, int H, int W,
+                                                        const float* sc, const float* sh, int gsize,
+                                                        float* __restrict__ out, long ostride, int bfi, int bfo) {
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, Q = Wo >> 2;
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= (unsigned)(Ho * Q)) return;
+  const unsigned yy = t / (unsigned)Q, q = t - yy * (unsigned)Q;
+  const int c = (int)blockIdx.y;
+  const long img = (long)blockIdx.z;
+  float s = 1.f, tt = 0.f;
+  if (sc) { const long g = (long)((unsigned)img / (unsigned)gsize); s = sc[g * C + c]; tt = sh[g * C + c]; }
+  const long p = img * istride + (long)c * H * W;
+  float v[4];
+  if (POOL) {
+    float a[8], b[8];
+    const long e = p + (long)(2 * yy) * W + 8 * q;
+    if (bfi) {
+      const uint4 u0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(y) + e);
+      const uint4 u1 = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(y) + e + W);
+      const unsigned w0[4] = {u0.x, u0.y, u0.z, u0.w}, w1[4] = {u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a[2 * k] = ua_lo(w0[k]); a[2 * k + 1] = ua_hi(w0[k]); b[2 * k] = ua_lo(w1[k]); b[2 * k + 1] = ua_hi(w1[k]); }
+    } else {
+      const float4 f0 = *reinterpret_cast<const float4*>(y + e), f1 = *reinterpret_cast<const float4*>(y + e + 4);
+      const float4 g0 = *reinterpret_cast<const float4*>(y + e + W), g1 = *reinterpret_cast<const float4*>(y + e + W + 4);
+      a[0] = f0.x; a[1] = f0.y; a[2] = f0.z; a[3] = f0.w; a[4] = f1.x; a[5] = f1.y; a[6] = f1.z; a[7] = f1.w;
+      b[0] = g0.x; b[1] = g0.y; b[2] = g0.z; b[3] = g0.w; b[4] = g1.x; b[5] = g1.y; b[6] = g1.z; b[7] = g1.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                     // (same order of max as the one-element kernel)
+      v[k] = fmaxf(fmaxf(a[2 * k] * s + tt, a[2 * k + 1] * s + tt), fmaxf(b[2 * k] * s + tt, b[2 * k + 1] * s + tt));
+  } else {
+    const float4 f = ua_ld4(y, p + (long)yy * W + 4 * q, bfi);
+    v[0] = f.x * s + tt; v[1] = f.y * s + tt; v[2] = f.z * s + tt; v[3] = f.w * s + tt;
+  }
+  if (sc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+  }
+  ua_st4(out, img * ostride + ((long)c * Ho + yy) * Wo + 4 * q, make_float4(v[0], v[1], v[2], v[3]), bfo);
+}
 extern "C" int mo_unet_act(const float* y, long istride, int C, long n_img, int H, int Wd, const float* sc,
                            const float* sh, int gsize, int pool, float* out, long ostride, int dtypes, void* stream) {
   MO_CHECK_ARG(y && out && C > 0 && n_img > 0 && H > 0 && Wd > 0 && gsize > 0);
   MO_CHECK_ARG((sc == nullptr) == (sh == nullptr));
   MO_CHECK_ARG(!pool || ((H % 2) == 0 && (Wd % 2) == 0));
   long total = n_img * C * (pool ? (H / 2) * (Wd / 2) : H * Wd);
+  const int Wo = pool ? Wd / 2 : Wd, Ho = pool ? H / 2 : H;
+  // (16-byte loads / stores: row pitches, plane and image strides in multiples of 8 elements cover both storage widths)
+  if ((Wo % 4) == 0 && (Wd % (pool ? 8 : 4)) == 0 && (long)Ho * (Wo / 4) >= 64 && C <= 65535 && n_img <= 65535 &&
+      (istride % 8) == 0 && (ostride % 8) == 0 && ((long)H * Wd) % 8 == 0 && ((long)Ho * Wo) % 8 == 0 &&
+      (((uintptr_t)y) & 15) == 0 && (((uintptr_t)out) & 15) == 0) {
+    const dim3 grid((unsigned)mo_cdiv((long)Ho * (Wo / 4), 256), (unsigned)C, (unsigned)n_img);
+    if (pool) hipLaunchKernelGGL(unet_act4_kernel<true>, grid, dim3(256), 0, ST(stream), y, istride, C, H, Wd, sc, sh, gsize, out,
+                                 ostride, (dtypes & MO_BF_IN0) != 0, (dtypes & MO_BF_OUT) != 0);
+    else hipLaunchKernelGGL(unet_act4_kernel<false>, grid, dim3(256), 0, ST(stream), y, istride, C, H, Wd, sc, sh, gsize, out,
+                            ostride, (dtypes & MO_BF_IN0) != 0, (dtypes & MO_BF_OUT) != 0);
+    return mo_launch_status();
+  }
   hipLaunchKernelGGL(unet_act_kernel, dim3(mo_cdiv(total, 256)), dim3(256), 0, ST(stream), y, istride, C, H, Wd, sc, sh,
                      gsize, pool, out, ostride, total, (dtypes & MO_BF_IN0) != 0, (dtypes & MO_BF_OUT) != 0);
   return mo_launch_status();
@@ -1316,13 +1373,23 @@ __global__ __launch_bounds__(256) void unet_act_bwd_apply2_kernel(const float* _
                                            const float* __restrict__ dp, long dpstride, const double* __restrict__ k12,
                                            float* __restrict__ dy, long dystride, long total8,
                                            const float* __restrict__ out_scale) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total8) return;
   const int Q2 = W >> 3;
-  const int q = 2 * (int)(i % Q2); long r = i / Q2;
-  const int yy = (int)(r % H); r /= H;
-  const int c = (int)(r % C); const long img = r / C;
-  const long g = img / gsize;
+  int q, yy, c; long img;
+  if (gridDim.y > 1 || gridDim.z > 1) {
+    // planar grid (x: the plane's 8-pixel pieces, y: channel, z: image): one 32-bit division per thread.  The linear form
+    // below costs seven 64-bit divisions by run-time values per 8 elements -- more instructions than the arithmetic
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= (unsigned)(H * Q2)) return;
+    const unsigned yu = t / (unsigned)Q2;
+    yy = (int)yu; q = 2 * (int)(t - yu * (unsigned)Q2); c = (int)blockIdx.y; img = (long)blockIdx.z;
+  } else {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    q = 2 * (int)(i % Q2); long r = i / Q2;
+    yy = (int)(r % H); r /= H;
+    c = (int)(r % C); img = r / C;
+  }
+  const long g = (long)((unsigned)img / (unsigned)gsize);
   const float s = sc[g * C + c], t = sh[g * C + c], mu = mean[g * C + c], rs = rstd[g * C + c];
   const long yoff = img * istride + (long)c * H * W, daoff = img * dastride + (long)c * H * W;
   const long dpoff = img * dpstride + (long)c * (H / 2) * (W / 2);
@@ -1393,7 +1460,11 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
     hipLaunchKernelGGL(unet_act_bwd_param_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, st, k12, G, C, gsize, HW, dgamma, dbeta);
   }
   const long total4 = n_img * C * (HW / 4);
-#define UA_APPLY2(YB, DAB, DPB, DYB) hipLaunchKernelGGL((unet_act_bwd_apply2_kernel<YB, DAB, DPB, DYB>), dim3(mo_cdiv(total4 / 2, 256)), \
+  // planes of >= 256 eight-pixel pieces (and C > 1 or several images, which is what tells the kernel): a grid per plane
+  const bool planar = (long)H * (Wd / 8) >= 256 && C <= 65535 && n_img <= 65535 && (C > 1 || n_img > 1);
+  const dim3 agrid = planar ? dim3((unsigned)mo_cdiv((long)H * (Wd / 8), 256), (unsigned)C, (unsigned)n_img)
+                            : dim3((unsigned)mo_cdiv(total4 / 2, 256));
+#define UA_APPLY2(YB, DAB, DPB, DYB) hipLaunchKernelGGL((unet_act_bwd_apply2_kernel<YB, DAB, DPB, DYB>), agrid, \
     dim3(256), 0, st, y, istride, C, H, Wd, gsize, gamma, mean, rstd, sc, sh, da, dastride, dp, dpstride, k12, dy, dystride, total4 / 2, out_scale)
   if (two) { if (fl.dy) UA_DISPATCH3(UA_APPLY2, true); else UA_DISPATCH3(UA_APPLY2, false); }
   else
