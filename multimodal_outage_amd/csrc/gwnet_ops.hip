@@ -1564,23 +1564,28 @@ extern "C" int mo_bn_finalize(const float* partial, long nblk, long count, const
 __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ h, long P,
                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                       float* __restrict__ part) {
-  __shared__ float sm[2][256];
-  const int c = threadIdx.x & 31, y = threadIdx.x >> 5;   // 8 row lanes
+  // a thread = 4 channels (one 16-byte load per tensor and row) x every 32nd row of the chunk: the one-float-per-lane form
+  // ran at 3.2 TB/s of its 1.4 GB (439 us per launch at batch 256)
+  __shared__ float sm[2][32][33];
+  const int c4 = (threadIdx.x & 7) * 4, y = threadIdx.x >> 3;   // 32 row lanes
   const long r0 = (long)blockIdx.x * 128;
   long r1 = r0 + 128; if (r1 > P) r1 = P;
-  const float mu = mean[c], rs = rstd[c];
-  float s1 = 0.f, s2 = 0.f;
-  for (long r = r0 + y; r < r1; r += 8) {
-    float d = dy[r * 32 + c];
-    float xh = (h[r * 32 + c] - mu) * rs;
-    s1 += d; s2 += d * xh;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c4), rs = *reinterpret_cast<const float4*>(rstd + c4);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (long r = r0 + y; r < r1; r += 32) {
+    const float4 d = *reinterpret_cast<const float4*>(dy + r * 32 + c4);
+    const float4 x = *reinterpret_cast<const float4*>(h + r * 32 + c4);
+    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+    s2.x += d.x * ((x.x - mu.x) * rs.x); s2.y += d.y * ((x.y - mu.y) * rs.y);
+    s2.z += d.z * ((x.z - mu.z) * rs.z); s2.w += d.w * ((x.w - mu.w) * rs.w);
   }
-  sm[0][threadIdx.x] = s1; sm[1][threadIdx.x] = s2;
+  sm[0][y][c4] = s1.x; sm[0][y][c4 + 1] = s1.y; sm[0][y][c4 + 2] = s1.z; sm[0][y][c4 + 3] = s1.w;
+  sm[1][y][c4] = s2.x; sm[1][y][c4 + 1] = s2.y; sm[1][y][c4 + 2] = s2.z; sm[1][y][c4 + 3] = s2.w;
   __syncthreads();
   if (threadIdx.x < 64) {
     const int which = threadIdx.x >> 5, ch = threadIdx.x & 31;
     float t = 0.f;
-    for (int q = 0; q < 8; ++q) t += sm[which][q * 32 + ch];
+    for (int q = 0; q < 32; ++q) t += sm[which][q][ch];
     part[(long)blockIdx.x * 64 + threadIdx.x] = t;
   }
 }
