@@ -127,7 +127,9 @@ static void wgrad_plan(int M, int N, long P, int& nsplit, int& kchunk) {
 extern "C" long mo_wgrad_ws_floats(int M, int N, long P) {
   int ns, kc; wgrad_plan(M, N, P, ns, kc);
   long a = (long)ns * M * N + (long)ns * M + 64;          // slabs + fused column-sum slabs
-  long b = (long)mo_cdiv(P, 512) * (M > N ? M : N) + 64;  // fallback column-sum partials
+  long b = (long)mo_cdiv(P, 512) * (M > N ? M : N) + 64;  // fallback column-sum partials ...
+  const long b2 = 1024L * (M > N ? M : N) + 64;           // ... which mo_colsum spreads over up to 1024 blocks (CSW_BLOCKS)
+  if (b2 > b) b = b2;
   long c = (long)RSW_MAX_WG * ((long)M * N + M) + 64;     // row-streaming kernel slabs
   if ((M % 32) || (N % 32) || (M / 32) * (N / 32) > 8) c = 0;
   a = a > b ? a : b;
@@ -181,13 +183,13 @@ __global__ void tcn_wgrad_reduce_kernel(const float* __restrict__ slab, long str
 // column sums: out[c] = sum_p X[p][c]   (bias gradients)
 // ------------------------------------------------------------------------------------------------
 #define CS_ROWS 512
-__global__ void colsum_partial_kernel(const float* __restrict__ X, long P, int C, float* __restrict__ part) {
+__global__ void colsum_partial_kernel(const float* __restrict__ X, long P, int C, float* __restrict__ part, int rpb) {
   __shared__ float sm[256];
   const int CW = C < 256 ? C : 256;
   const int RY = 256 / CW;
   const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
-  long r0 = (long)blockIdx.x * CS_ROWS;
-  long r1 = r0 + CS_ROWS; if (r1 > P) r1 = P;
+  long r0 = (long)blockIdx.x * rpb;
+  long r1 = r0 + rpb; if (r1 > P) r1 = P;
   for (int c0 = 0; c0 < C; c0 += CW) {
     int c = c0 + tx;
     float s = 0.f;
@@ -268,8 +270,13 @@ extern "C" int mo_colsum(const float* X, long P, int C, float* out, float* ws, v
                        (long)C);
     return mo_launch_status();
   }
-  int nb = mo_cdiv(P, CS_ROWS);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, ST(stream), X, P, C, ws);
+  // rows per block: few rows (the 67-node graph's 134 .. 1072 positions) are spread over up to CSW_BLOCKS blocks -- two
+  // blocks of 512 rows walked one dependent load after the other took 139 us for 0.5 MB
+  int rpb = (int)mo_cdiv(P, (long)CSW_BLOCKS);
+  if (rpb < 4) rpb = 4;
+  if (rpb > CS_ROWS) rpb = CS_ROWS;
+  int nb = mo_cdiv(P, rpb);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, ST(stream), X, P, C, ws, rpb);
   hipLaunchKernelGGL(slab_reduce_kernel, slab_grid(C), dim3(256), 0, ST(stream), ws, (long)C, nb, out,
                      (long)C);
   return mo_launch_status();
@@ -929,7 +936,7 @@ extern "C" int mo_tcn_bwd(const float* h_prev, const float* scale, const float* 
       (void)hipMemcpyAsync(dbg, db64 + 32, 32 * sizeof(float), hipMemcpyDeviceToDevice, st);
     } else {
       int nb = mo_cdiv(Pout, CS_ROWS);
-      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, dpre_ws, Pout, 64, ws2);
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, dpre_ws, Pout, 64, ws2, CS_ROWS);
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, ws2, (long)64, nb, dbf, (long)32);
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, ws2 + 32, (long)64, nb, dbg, (long)32);
     }

@@ -1477,19 +1477,22 @@ extern "C" int mo_unet_act_bwd(const float* y, long istride, int C, long n_img, 
 }
 
 // per-channel sum over images and pixels of an NCHW tensor (bias gradients): out[c] = sum_{img,pix} x
+// one wave per channel, lanes over the images (fixed order: lane-strided partial sums, then a butterfly): a thread per
+// channel walking the images one dependent load after the other took 74 us at one window, 318 us at four
 __global__ void nchw_chan_sum_final_kernel(const float* __restrict__ stats, long n_img, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
-  for (long i = 0; i < n_img; ++i) s += stats[(i * C + c) * 2];
-  out[c] = (float)s;
+  for (long i = lane; i < n_img; i += 64) s += stats[(i * C + c) * 2];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[c] = (float)s;
 }
 extern "C" int mo_nchw_channel_sum(const float* x, long istride, int C, long n_img, int HW, float* out, float* ws,
                                    void* stream) {
   MO_CHECK_ARG(x && out && ws);
   int rc = mo_nchw_stats(x, istride, C, n_img, HW, ws, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(nchw_chan_sum_final_kernel, dim3(mo_cdiv(C, 64)), dim3(64), 0, ST(stream), ws, n_img, C, out);
+  hipLaunchKernelGGL(nchw_chan_sum_final_kernel, dim3(C), dim3(64), 0, ST(stream), ws, n_img, C, out);
   return mo_launch_status();
 }
 
