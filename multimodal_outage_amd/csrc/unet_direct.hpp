@@ -454,7 +454,9 @@ __global__ __launch_bounds__(256) void uw_wgrad_mfma_kernel(UdWgradArgs a) {
 // the accumulators, as in ud_conv3x3_kernel.  The data gradient is this kernel on dy with the flipped weights.
 // ------------------------------------------------------------------------------------------------
 #define UX_CIC 8
-template <int MB, int TW>
+template <int MB, int TW, bool FULL = false>      // FULL: the input channel count is a multiple of 8 (no partial last chunk:
+                                                  // the k loop needs no masks; as a run-time branch the second loop copy
+                                                  // cost the 32-pixel instantiations 15 %)
 __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
   constexpr int TH = 256 / TW;
   constexpr int LDT = TW + 8;
@@ -520,17 +522,35 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
           for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bv, acc[mb][nb], 0, 0, 0);
         }
       }
+    } else if constexpr (FULL) {                                 // full chunks only: every lane's k is inside, nothing to mask
+#pragma unroll
+      for (int i = 0; i < UX_CIC * 9 / 4; ++i) {
+        float af[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) af[mb] = wsm[kstep_w[i] + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const float bv = xs[kstep_b[i] + poff[nb]];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bv, acc[mb][nb], 0, 0, 0);
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < UX_CIC * 9 / 4; ++i) {
         if (4 * i >= nk) break;                                  // (a last chunk of fewer than 8 channels)
-        const float m = (4 * i + lk < nk) ? 1.f : 0.f;
+        // lanes past the chunk's last k (a last chunk of fewer than 8 channels) multiply by zero -- but they must read
+        // FINITE values: the LDS beyond this chunk's data holds whatever an earlier kernel left there (a NaN pattern made
+        // 0 * NaN = NaN in a 1-channel 16 x 16 case, only after other tests had run), so they re-read step 0's operands
+        const bool ok = 4 * i + lk < nk;
+        const float m = ok ? 1.f : 0.f;
+        const int wo = ok ? kstep_w[i] : kstep_w[0], bo = ok ? kstep_b[i] : kstep_b[0];
         float af[MB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) af[mb] = wsm[kstep_w[i] + mb * 16] * m;
+        for (int mb = 0; mb < MB; ++mb) af[mb] = wsm[wo + mb * 16] * m;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-          const float bv = xs[kstep_b[i] + poff[nb]];
+          const float bv = xs[bo + poff[nb]];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bv, acc[mb][nb], 0, 0, 0);
         }

@@ -296,8 +296,11 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     a.off0 = reinterpret_cast<const long*>(in0_off);
     hipStream_t st = ST(stream);
     dim3 grid(Wd / uxw, H / (256 / uxw), (unsigned)n_img);
-#define UX_LAUNCH(MB) do { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32>), grid, dim3(256), 0, st, a); \
-                           else hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 16>), grid, dim3(256), 0, st, a); } while (0)
+#define UX_LAUNCH(MB) do { \
+    if (Ci % UX_CIC == 0) { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32, true>), grid, dim3(256), 0, st, a); \
+                            else hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 16, true>), grid, dim3(256), 0, st, a); } \
+    else { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32>), grid, dim3(256), 0, st, a); \
+           else hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 16>), grid, dim3(256), 0, st, a); } } while (0)
     if (Co <= 16) UX_LAUNCH(1); else if (Co <= 32) UX_LAUNCH(2); else if (Co <= 48) UX_LAUNCH(3); else UX_LAUNCH(4);
 #undef UX_LAUNCH
     return mo_launch_status();

@@ -89,6 +89,29 @@ def test_conv3x3_fwd_bwd(L, n, gs, C0, C1, Co, H, W, bf):
     close(dW, Wt.grad, what='conv dW')
 
 
+@pytest.mark.parametrize('n,C0,Co,H,W', [(6, 1, 4, 16, 16), (2, 13, 8, 16, 16), (3, 20, 32, 32, 32), (2, 5, 16, 32, 32)])
+def test_conv3x3_partial_channel_chunk_ignores_stale_lds(L, n, C0, Co, H, W):
+    """The deep-level conv stages 8 input channels at a time; in a last chunk of fewer than 8 the lanes past its last k
+    multiply by zero -- and must not read what an EARLIER kernel left in LDS (0 * NaN = NaN: an order-dependent failure of
+    the suite in round 3).  A launch on NaN data of 8 channels leaves NaN patterns in every staged LDS word; the ragged
+    launch right behind it on the same CUs must still be finite and right."""
+    lib = L.load()
+    nb = 1200 * 256 // (H * W) + n                        # (enough workgroups to visit every CU several times)
+    nanx = torch.full((nb, 8, H, W), float('nan'), device='cuda')
+    nanw = torch.full((Co, 8, 3, 3), float('nan'), device='cuda')
+    junk = torch.empty(nb, Co, H, W, device='cuda')
+    x = rand(91, (n, C0, H, W)); Wt = rand(92, (Co, C0, 3, 3)) / np.sqrt(9 * C0)
+    xd, Wd_ = dev(x), dev(Wt)
+    out = torch.empty(n, Co, H, W, device='cuda')
+    for _ in range(3):                                        # (several rounds: every CU sees both launches)
+        L.call('mo_conv3x3_fwd', L.ptr(nanx), 8, 8 * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(nanw), Co, nb, H, W,
+               L.ptr(junk), Co * H * W, None, 0, None, L.stream())
+        L.call('mo_conv3x3_fwd', L.ptr(xd), C0, C0 * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wd_), Co, n, H, W,
+               L.ptr(out), Co * H * W, None, 0, None, L.stream())
+        assert bool(torch.isfinite(out).all())
+        close(out, F.conv2d(x, Wt, None, padding=1), tol=1e-4, what='conv fwd behind a NaN launch')
+
+
 @pytest.mark.parametrize('n,gs,C0,C1,Co,H,W', [(4, 2, 4, 0, 4, 16, 64), (3, 1, 13, 0, 4, 32, 64), (2, 2, 4, 4, 4, 16, 128),
                                                 (2, 1, 8, 0, 8, 32, 128), (2, 2, 8, 8, 8, 16, 64), (2, 1, 8, 0, 16, 64, 64),
                                                 (2, 1, 16, 16, 16, 16, 64), (3, 3, 16, 0, 32, 16, 64), (2, 1, 16, 16, 32, 32, 64), (2, 1, 20, 0, 32, 32, 64),
