@@ -44,6 +44,7 @@ struct UdConvArgs {
   int bf0, bf1, bfo;       // storage of in0 / in1 / out: 0 fp32, 1 bf16 (strides are in ELEMENTS either way)
   const long* off0 = nullptr;   // optional per-image ELEMENT offsets of in0 (image img at in0 + off0[img] instead of
                                 // in0 + img * is0): the network input as the permuted batch view of lit.py:31, no copy
+  int cosplit = 1;              // ux_conv3x3_mfma_kernel: workgroups per tile, each with its own 16*MB output channels
 };
 template <class A> __device__ __forceinline__ long ud_base0(const A& a, long img) { return a.off0 ? a.off0[img] : img * a.is0; }
 
@@ -467,7 +468,11 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
   __shared__ __attribute__((aligned(16))) float wsm[UX_CIC * 9 * CP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const long img = blockIdx.z;
+  // cosplit workgroups share a tile, each with 16 * MB of the output channels: 134 images of 16 x 16 pixels are 134
+  // workgroups of one wave per SIMD on 256 compute units -- nothing overlapped the staging of a chunk (90 us for 35 us of
+  // MFMA issue at 64 -> 64 channels)
+  const long img = blockIdx.z / a.cosplit;
+  const int co0 = (int)(blockIdx.z - img * a.cosplit) * CP;
   const long grp = img / a.gsize;
   const int Ci = a.C0 + a.C1;
   const int lj = lane & 15, lk = lane >> 4;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
     for (int idx = tid; idx < nc * 9 * CP; idx += 256) {
       const int k = idx / CP, co = idx - k * CP;
       const int c = k / 9, tap = k - 9 * c;
-      wsm[idx] = (co < a.Co) ? a.W[((long)co * Ci + c0 + c) * 9 + tap] : 0.f;
+      wsm[idx] = (co0 + co < a.Co) ? a.W[((long)(co0 + co) * Ci + c0 + c) * 9 + tap] : 0.f;
     }
     __syncthreads();
     const int nk = nc * 9;
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = mb * 16 + lk * 4 + r;
+      const int co = co0 + mb * 16 + lk * 4 + r;
       if (co < a.Co) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
@@ -588,9 +593,9 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
         if (lj == 0) { const int co = mb * 16 + lk * 4 + r; red[wave][2 * co] = s1; red[wave][2 * co + 1] = s2; }
       }
     __syncthreads();
-    if (tid < 2 * CP && (tid >> 1) < a.Co) {
+    if (tid < 2 * CP && co0 + (tid >> 1) < a.Co) {
       const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x, ntile = (long)gridDim.x * gridDim.y;
-      a.stats[((img * ntile + tile) * a.Co + (tid >> 1)) * 2 + (tid & 1)] =
+      a.stats[((img * ntile + tile) * a.Co + co0 + (tid >> 1)) * 2 + (tid & 1)] =
           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
   }

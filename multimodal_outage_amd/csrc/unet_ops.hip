@@ -32,6 +32,7 @@ static int mo_opt_fc_wide = 1;            // FC kernels: 1 = two 16-column block
 static int mo_opt_ub_no_pack = 0;         // A/B switch: 1 = thin outputs on the unpacked D[pixel][co] kernel
 static int mo_opt_ub_ipw = 0;             // experiment: images per workgroup of the bf16 conv (0 = heuristic)
 static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
+static int mo_opt_ux_split = 0;          // workgroups per tile of the fp32 matrix-pipe conv (output channels dealt out): 0 = heuristic
 extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!name) return MO_EINVAL;
   if (!strcmp(name, "no_mfma_wgrad")) { mo_opt_no_mfma_wgrad = value; return MO_OK; }
@@ -43,6 +44,7 @@ extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!strcmp(name, "ub_no_pack")) { mo_opt_ub_no_pack = value; return MO_OK; }
   if (!strcmp(name, "ub_ipw")) { mo_opt_ub_ipw = value; return MO_OK; }
   if (!strcmp(name, "ux_min_co")) { mo_opt_ux_min_co = value; return MO_OK; }
+  if (!strcmp(name, "ux_split")) { mo_opt_ux_split = value; return MO_OK; }
   return MO_EINVAL;
 }
 
@@ -180,6 +182,7 @@ static int ux_tw(int Co, long n_img, int H, int Wd) {
   if ((Wd % 16) == 0 && (H % 16) == 0) return 16;
   return 0;
 }
+#define UX_SPLIT_BELOW 2048               // tiles below which the output channels of a tile go to several workgroups
 static bool ux_preferred(int Co, int H, int Wd) { return Co >= mo_opt_ux_min_co || H < 32 || Wd < 32; }
 // bf16 matrix-pipe conv (unet_bf16.hpp): images that tile exactly into 16 x 64 (or 16 x 32) pixels, <= 32 channels either side
 // (32-pixel-wide tiles -- the 32 x 32 level -- are built and tested but OFF by default, mo_unet_set_option("ub_min_w", 32):
@@ -295,13 +298,23 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     a.W = W; a.out = out; a.os = ostride; a.Co = Co; a.H = H; a.Wd = Wd; a.gsize = gsize < 1 ? 1 : gsize;
     a.off0 = reinterpret_cast<const long*>(in0_off);
     hipStream_t st = ST(stream);
-    dim3 grid(Wd / uxw, H / (256 / uxw), (unsigned)n_img);
+    // 16-channel output blocks per workgroup: all of them while the grid fills the chip, else dealt over 2 or 4
+    // workgroups per tile (each stages the same halo from L2)
+    const int blocks = mo_cdiv(Co, 16);
+    const long tiles = (long)(Wd / uxw) * (H / (256 / uxw)) * n_img;
+    int split = 1;
+    if (mo_opt_ux_split > 0) split = mo_opt_ux_split;
+    else while (split < 4 && tiles * split < UX_SPLIT_BELOW && blocks % (2 * split) == 0) split *= 2;
+    if (split > blocks || blocks % split != 0 || n_img * split >= 65536) split = 1;
+    a.cosplit = split;
+    const int wg_blocks = blocks / split;
+    dim3 grid(Wd / uxw, H / (256 / uxw), (unsigned)(n_img * split));
 #define UX_LAUNCH(MB) do { \
     if (Ci % UX_CIC == 0) { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32, true>), grid, dim3(256), 0, st, a); \
                             else hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 16, true>), grid, dim3(256), 0, st, a); } \
     else { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32>), grid, dim3(256), 0, st, a); \
            else hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 16>), grid, dim3(256), 0, st, a); } } while (0)
-    if (Co <= 16) UX_LAUNCH(1); else if (Co <= 32) UX_LAUNCH(2); else if (Co <= 48) UX_LAUNCH(3); else UX_LAUNCH(4);
+    if (wg_blocks == 1) UX_LAUNCH(1); else if (wg_blocks == 2) UX_LAUNCH(2); else if (wg_blocks == 3) UX_LAUNCH(3); else UX_LAUNCH(4);
 #undef UX_LAUNCH
     return mo_launch_status();
   }

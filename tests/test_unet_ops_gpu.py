@@ -112,6 +112,35 @@ def test_conv3x3_partial_channel_chunk_ignores_stale_lds(L, n, C0, Co, H, W):
         close(out, F.conv2d(x, Wt, None, padding=1), tol=1e-4, what='conv fwd behind a NaN launch')
 
 
+@pytest.mark.parametrize('n,C0,Co,H,W', [(3, 24, 64, 16, 16), (2, 32, 64, 32, 32), (5, 12, 32, 16, 16), (2, 16, 48, 16, 32),
+                                        (2, 8, 40, 32, 32)])
+def test_conv3x3_output_channels_dealt_over_workgroups(L, n, C0, Co, H, W):
+    """The deep-level conv deals the 16-channel output blocks of a tile over 1, 2 or 4 workgroups when the grid would not
+    fill the chip (option ux_split; 0 = the heuristic).  Every split computes each output element with the same operands
+    in the same order: outputs and BatchNorm statistics rows are bit-identical to the unsplit launch (a split the block
+    count does not divide falls back to it)."""
+    lib = L.load()
+    x = rand(71, (n, C0, H, W)); Wt = rand(72, (Co, C0, 3, 3)) / np.sqrt(9 * C0)
+    xd, Wd_ = dev(x), dev(Wt)
+    ntile = lib.mo_conv3x3_stats_tiles(Co, n, H, W)
+    assert ntile > 0
+    res = {}
+    try:
+        for split in (1, 2, 4, 0):
+            L.call('mo_unet_set_option', b'ux_split', split)
+            out = torch.full((n, Co, H, W), float('nan'), device='cuda')
+            stats = torch.full((n, ntile, Co, 2), float('nan'), device='cuda')
+            L.call('mo_conv3x3_fwd', L.ptr(xd), C0, C0 * H * W, None, None, 0, None, 0, 0, None, None, 0, 1, L.ptr(Wd_), Co, n, H, W,
+                   L.ptr(out), Co * H * W, L.ptr(stats), 0, None, L.stream())
+            res[split] = (out.cpu(), stats.cpu())
+    finally:
+        L.call('mo_unet_set_option', b'ux_split', 0)
+    close(res[1][0], F.conv2d(x, Wt, None, padding=1), tol=1e-4, what='conv fwd, one workgroup per tile')
+    for split in (2, 4, 0):
+        assert torch.equal(res[split][0], res[1][0]), f'outputs differ at ux_split={split}'
+        assert torch.equal(res[split][1], res[1][1]), f'statistics rows differ at ux_split={split}'
+
+
 @pytest.mark.parametrize('n,gs,C0,C1,Co,H,W', [(4, 2, 4, 0, 4, 16, 64), (3, 1, 13, 0, 4, 32, 64), (2, 2, 4, 4, 4, 16, 128),
                                                 (2, 1, 8, 0, 8, 32, 128), (2, 2, 8, 8, 8, 16, 64), (2, 1, 8, 0, 16, 64, 64),
                                                 (2, 1, 16, 16, 16, 16, 64), (3, 3, 16, 0, 32, 16, 64), (2, 1, 16, 16, 32, 32, 64), (2, 1, 20, 0, 32, 32, 64),
