@@ -454,6 +454,12 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
     const SgLayer& Ly = a.ly[li];
     int wave = wave_; asm volatile("" : "+v"(wave));      // (see sg_fwd_kernel)
     const int wrot = (wave + SG_WAVES - (mtiles % SG_WAVES)) % SG_WAVES;     // first weight tile of this wave
+#ifdef SG_TIMING
+    long long tb0 = wall_clock64(); float* tsb = a.stats + ((long)blockIdx.x * a.L + li) * 6 * 32 + 160 + 16; int tkb = 0;
+#define SG_TB() do { if (tid == 0) tsb[tkb] = (float)(wall_clock64() - tb0); ++tkb; } while (0)
+#else
+#define SG_TB() do {} while (0)
+#endif
     float* slab = a.slab + ((long)blockIdx.x * a.L + li) * slabL;
     const bool has_dh = li < a.L - 1;            // the last layer's gcn / bn output is dead (graph_wavenet.py:252)
     // ---- weights
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
       const float* st = a.stats + ((long)blockIdx.x * a.L + li) * 6 * 32;
       bnk[96 + tid] = st[64 + tid]; bnk[128 + tid] = st[96 + tid];
     }
-    __syncthreads();
+    __syncthreads(); SG_TB();
     const float* xin = li == 0 ? a.h0 : a.hs + (long)(li - 1) * rows * 32;
     const float* gl = a.gcat + li * 32;
     const float* hl = a.hs + (long)li * rows * 32;
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
         }
         red[tr * 33 + tc] = s1; red[32 * 33 + tr * 33 + tc] = s2;
       }
-      __syncthreads();
+      __syncthreads(); SG_TB();
       if (tid < 32) {
         double s1 = 0.0, s2 = 0.0;
         for (int k = 0; k < SG_NR; ++k) { s1 += red[k * 33 + tid]; s2 += red[32 * 33 + k * 33 + tid]; }
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
         bnk[tid] = Ly.gamma[tid] * bnk[128 + tid];
         bnk[32 + tid] = (float)(s1 / P); bnk[64 + tid] = (float)(s2 / P);
       }
-      __syncthreads();
+      __syncthreads(); SG_TB();
       // ---- R2: dh = gamma rstd (dxo - k1 - xhat k2); bias gradient of the mlp = sum of the dropout-masked dh
       {
         double s3 = 0.0;
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
         }
         red[tr * 33 + tc] = s3;
       }
-      __syncthreads();
+      __syncthreads(); SG_TB();
       if (tid < 32) {
         double s3 = 0.0;
         for (int k = 0; k < SG_NR; ++k) s3 += red[k * 33 + tid];
@@ -561,6 +567,9 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
           }
         }
       }
+#ifdef SG_TIMING
+      if (tid == 0) tsb[12] = (float)(wall_clock64() - tb0);     // (wave 0: its strip of the mlp data gradient done)
+#endif
       //      weights: dWm[co][e*32 + ci] = sum_p dhm[p][co] src_e[p][ci]
       for (int jw = wrot; jw < 2 * 2 * NE; jw += SG_WAVES) {
         const int ct = jw / (2 * NE), nt = jw - ct * (2 * NE);
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
           }
         }
       }
-      __syncthreads();
+      __syncthreads(); SG_TB();
       if (ND > 0) {
         // ---- N1: dx1_d += A_d dx2_d   (a job = 16 nodes x the 32 channels of one time step)
         for (int job = wave; job < ND * ntn * T; job += SG_WAVES) {
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
             if (v < N) { float* o = dx1 + g.nrow(v, tt) * 32 + l16; o[0] += acc0[i]; o[16] += acc1[i]; }
           }
         }
-        __syncthreads();
+        __syncthreads(); SG_TB();
         // ---- N2: dg += sum_d A_d dx1_d ;  dA += x1^T-products of the adaptive support
         for (int job = wave; job < ntn * T; job += SG_WAVES) {
           const int mt = job / T, tt = job - mt * T;
@@ -661,6 +670,9 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
             if (v < N) { float* o = a.dg + g.nrow(v, tt) * 32 + l16; o[0] += acc0[i]; o[16] += acc1[i]; }
           }
         }
+#ifdef SG_TIMING
+        if (tid == 0) tsb[13] = (float)(wall_clock64() - tb0);   // (wave 0: its hop job done, dA tiles next)
+#endif
         if (nAt) {
           const int d = a.adaptive_dense;
           const float* x1 = a.xs + (((long)li * ND + d) * 2) * rows * 32;
@@ -685,14 +697,14 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
             }
           }
         }
-        __syncthreads();
+        __syncthreads(); SG_TB();
       }
     } else {
       // last layer: only the skip path reaches g
       for (int pl = tr; pl < P; pl += SG_NR) { const long r = g.row(pl); a.dg[r * 32 + tc] = a.dgskip[r * ldg + li * 32 + tc]; }
       if (tid < 32) { slab[SG_S_GA + tid] = 0.f; slab[SG_S_BE + tid] = 0.f; slab[SG_S_BM + tid] = 0.f; }
       for (int i = tid; i < 32 * 32 * (1 + 2 * a.nsup); i += SG_THREADS) slab[SG_S_WM + i] = 0.f;
-      __syncthreads();
+      __syncthreads(); SG_TB();
     }
 
     // ---- T1: recompute the pre-activations, form their gradients
@@ -739,7 +751,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
       t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
       if (q == 0) { part[wave * 64 + nh * 16 + l16] = t1; part[wave * 64 + 32 + nh * 16 + l16] = t2; }
     }
-    __syncthreads();
+    __syncthreads(); SG_TB();
     if (tid < 64) {
       double s = 0.0;
       for (int w = 0; w < SG_WAVES; ++w) s += (double)part[w * 64 + tid];
@@ -786,7 +798,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_bwd_kernel(SgArgs a) {
         slab[(c < 32 ? SG_S_WF + c * 32 : SG_S_WG + (c - 32) * 32) + ci] = acc[i];
       }
     }
-    __syncthreads();
+    __syncthreads(); SG_TB();
     // the gradient w.r.t. the layer input x_li = BN_{li-1}(h_{li-1}) is now in dxo: the next iteration's R phases read it
   }
   if (nAt) {
