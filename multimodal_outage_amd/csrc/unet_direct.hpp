@@ -45,6 +45,7 @@ struct UdConvArgs {
   const long* off0 = nullptr;   // optional per-image ELEMENT offsets of in0 (image img at in0 + off0[img] instead of
                                 // in0 + img * is0): the network input as the permuted batch view of lit.py:31, no copy
   int cosplit = 1;              // ux_conv3x3_mfma_kernel: workgroups per tile, each with its own 16*MB output channels
+  long n_img = 0;               // (cosplit > 1: the grid is one-dimensional and padded; workgroups past the last tile leave)
 };
 template <class A> __device__ __forceinline__ long ud_base0(const A& a, long img) { return a.off0 ? a.off0[img] : img * a.is0; }
 
@@ -467,12 +468,26 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[UX_CIC * PS];
   __shared__ __attribute__((aligned(16))) float wsm[UX_CIC * 9 * CP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   // cosplit workgroups share a tile, each with 16 * MB of the output channels: 134 images of 16 x 16 pixels are 134
   // workgroups of one wave per SIMD on 256 compute units -- nothing overlapped the staging of a chunk (90 us for 35 us of
-  // MFMA issue at 64 -> 64 channels)
-  const long img = blockIdx.z / a.cosplit;
-  const int co0 = (int)(blockIdx.z - img * a.cosplit) * CP;
+  // MFMA issue at 64 -> 64 channels).  Their grid is one-dimensional: workgroup L serves tile 8 (L / 8S) + L % 8, split
+  // (L % 8S) / 8 -- the S workgroups of a tile are 8 apart, i.e. on the SAME XCD (round-robin dispatch), and the tile's halo
+  // comes from memory once, not once per L2.
+  int bx = blockIdx.x, by = blockIdx.y, co0 = 0;
+  long img = blockIdx.z;
+  const int gx = a.Wd / TW, gy = a.H / TH;
+  if (a.cosplit > 1) {
+    const int S8 = 8 * a.cosplit;
+    const long c = blockIdx.x / S8;
+    const int r = (int)(blockIdx.x - c * S8);
+    const long tg = c * 8 + (r & 7);
+    if (tg >= (long)gx * gy * a.n_img) return;
+    co0 = (r >> 3) * CP;
+    img = tg / (gx * gy);
+    const int t = (int)(tg - img * (gx * gy));
+    by = t / gx; bx = t - by * gx;
+  }
+  const int x0 = bx * TW, y0 = by * TH;
   const long grp = img / a.gsize;
   const int Ci = a.C0 + a.C1;
   const int lj = lane & 15, lk = lane >> 4;
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(256) void ux_conv3x3_mfma_kernel(UdConvArgs a) {
       }
     __syncthreads();
     if (tid < 2 * CP && co0 + (tid >> 1) < a.Co) {
-      const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x, ntile = (long)gridDim.x * gridDim.y;
+      const long tile = (long)by * gx + bx, ntile = (long)gx * gy;
       a.stats[((img * ntile + tile) * a.Co + co0 + (tid >> 1)) * 2 + (tid & 1)] =
           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }

@@ -305,10 +305,11 @@ extern "C" int mo_conv3x3_fwd(const float* in0, int C0, long istride0, const flo
     int split = 1;
     if (mo_opt_ux_split > 0) split = mo_opt_ux_split;
     else while (split < 4 && tiles * split < UX_SPLIT_BELOW && blocks % (2 * split) == 0) split *= 2;
-    if (split > blocks || blocks % split != 0 || n_img * split >= 65536) split = 1;
-    a.cosplit = split;
+    if (split > blocks || blocks % split != 0 || (tiles + 7) / 8 * 8 * split >= (1L << 31)) split = 1;
+    a.cosplit = split; a.n_img = n_img;
     const int wg_blocks = blocks / split;
-    dim3 grid(Wd / uxw, H / (256 / uxw), (unsigned)(n_img * split));
+    dim3 grid(Wd / uxw, H / (256 / uxw), (unsigned)n_img);
+    if (split > 1) grid = dim3((unsigned)((tiles + 7) / 8 * 8 * split), 1, 1);
 #define UX_LAUNCH(MB) do { \
     if (Ci % UX_CIC == 0) { if (uxw == 32) hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 32, true>), grid, dim3(256), 0, st, a); \
                             else hipLaunchKernelGGL((ux_conv3x3_mfma_kernel<MB, 16, true>), grid, dim3(256), 0, st, a); } \
