@@ -21,8 +21,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--opt', action='append', default=[], help='name=value for mo_unet_set_option (A/B switches)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16', help="activation storage (Modified_UNET.act_dtype)")
+    ap.add_argument('--main-priority', type=int, default=0, help='run the step on a stream of this priority (-1 = high): the '
+                    'weight-gradient lane (priority 0) then only gets what the data-flow chain leaves free (A/B)')
     ap.add_argument('--two-step', action='store_true', help='model(x) -> yhat -> loss kernel instead of the fused tail (A/B)')
     a = ap.parse_args()
+    if a.main_priority:
+        print('stream priority range', torch.cuda.Stream.priority_range(), file=sys.stderr)
+        torch.cuda.set_stream(torch.cuda.Stream(priority=a.main_priority))
     import multimodal_outage_amd._lib as L
     L.load()
     for o in a.opt:
