@@ -67,7 +67,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ub_rsrc(const void* p, long by
 // B = the channels-last tile as it lies in LDS (the (DX + 2) * CP values of a group and row are contiguous).  One MFMA
 // tile then covers 16 * DX pixels of a row for all output channels: 3 instead of 8 MFMAs (and LDS fragment reads) per 64
 // pixels at Ci = Co = 4, a lane ends up with DX consecutive pixels of a channel, and every lane has an output.
-template <int CP, int NB, int RB, bool TWO, int TW = UB_TW, int DX = 1>   // padded input channels (4, 8, 16, 32), blocks of 16 output
+template <int CP, int NB, int RB, bool TWO, int TW = UB_TW, int DX = 1, bool SPREAD = false>   // padded input channels (4, 8, 16, 32), blocks of 16 output
                                                // channels, rows per band, TWO: two views of CP/2 channels each (the skip /
                                                // up concat), TW: tile width (64; 32 for 32-pixel-wide images), DX: pixels
                                                // per MFMA row group (1; 4 / 2 for Co <= 4 / 8, NB = 1, TW = 64, CP <= 16)
@@ -150,11 +150,28 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
   // staging tasks of this thread: the same for every image and band.  toff: byte offset inside the image of
   // (first channel of the quad, row y0 + r - 1, column x); trow: that row, or far outside for lanes without a task /
   // columns outside the image; tdst: LDS element of (row r, column, channel quad)
-  int toff[NTS], trow[NTS], tcol[NTS], tdst[NTS];
+  // Lane order of the tasks (CP >= 8): channel quad fastest, then pixel quad, then row, and a lane writes its four pixels
+  // in an order rotated by a few bits of its pixel-quad index (trot).  A pixel is CP * 2 = 16 / 32 / 64 bytes of LDS, a
+  // pixel quad 64 / 128 / 256: with the pixel quad fastest and every lane writing pixel j in the j-th instruction the
+  // lanes of a ds_write_b64 were 128 bytes apart at CP = 16 -- one bank pair for a whole lane group (the counters of the
+  // 13-channel first conv: 324 M conflict cycles against 79 M LDS-active ones; the 4-channel layers, whose lanes write 32
+  // contiguous bytes each, had 5 M).  A ds_write_b64 is served in four groups of 16 contiguous lanes over 32 banks (a
+  // 128-byte row): now the 16 lanes of a group cover its 16 eight-byte slots -- (channel quad) x (rotated pixel) [x a low
+  // pixel-quad bit at CP = 8].
+  constexpr int NQB = CP == 8 ? 1 : 0;                    // low pixel-quad bits that still select a slot of the 128-byte row
+  // A template variant (SPREAD) launched for an fp32 first view only -- the 13-channel network input: on the bf16-stored
+  // layers the stage is bound by instruction issue and the selects of the rotation cost more than the conflicts (16 -> 16
+  // at 64^2: 29 -> 31 us, and 33 us with the choice as a run-time flag; the first conv: 206 -> 189 us).
+  static_assert(!SPREAD || CP >= 8, "the spread staging order is for >= 8 padded channels");
+  constexpr bool spread = SPREAD;
+  int toff[NTS], trow[NTS], tcol[NTS], tdst[NTS], trot[NTS];
 #pragma unroll
   for (int t = 0; t < NTS; ++t) {
     const int idx = tid + t * 256;
-    const int cq = idx / (NR * QH), r2 = idx - cq * (NR * QH), r = r2 / QH, q = r2 - r * QH;
+    int cq, r, q;
+    if (spread) { cq = idx % CQS; const int r2 = idx / CQS; r = r2 / QH; q = r2 - r * QH; }
+    else { cq = idx / (NR * QH); const int r2 = idx - cq * (NR * QH); r = r2 / QH; q = r2 - r * QH; }
+    trot[t] = spread ? (q >> NQB) & 3 : 0;
     tcol[t] = 4 * q - 4;                                  // column relative to the tile
     toff[t] = (cq * 4 * a.H + y0 + r - 1) * a.Wd + tcol[t];   // in ELEMENTS (the two views may differ in width), tile 0
     trow[t] = y0 + r - 1;
@@ -246,8 +263,18 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
           *reinterpret_cast<uint4*>(dst) = make_uint4(p0.x, p0.y, p1.x, p1.y);
           *reinterpret_cast<uint4*>(dst + 8) = make_uint4(p2.x, p2.y, p3.x, p3.y);
         } else {
-          *reinterpret_cast<uint2*>(dst) = p0; *reinterpret_cast<uint2*>(dst + CP) = p1;
-          *reinterpret_cast<uint2*>(dst + 2 * CP) = p2; *reinterpret_cast<uint2*>(dst + 3 * CP) = p3;
+          if constexpr (!spread) {
+            *reinterpret_cast<uint2*>(dst) = p0; *reinterpret_cast<uint2*>(dst + CP) = p1;
+            *reinterpret_cast<uint2*>(dst + 2 * CP) = p2; *reinterpret_cast<uint2*>(dst + 3 * CP) = p3;
+          } else {
+            // instruction n writes pixel (n + trot) & 3 of the lane's quad
+            const int rot = trot[tl];
+            const bool r1 = rot & 1, r2 = rot & 2;
+            const uint2 a0 = r1 ? p1 : p0, a1 = r1 ? p2 : p1, a2 = r1 ? p3 : p2, a3 = r1 ? p0 : p3;     // rotated by rot & 1
+            const uint2 w0 = r2 ? a2 : a0, w1 = r2 ? a3 : a1, w2 = r2 ? a0 : a2, w3 = r2 ? a1 : a3;     // ... and by rot & 2
+            *reinterpret_cast<uint2*>(dst + ((rot + 0) & 3) * CP) = w0; *reinterpret_cast<uint2*>(dst + ((rot + 1) & 3) * CP) = w1;
+            *reinterpret_cast<uint2*>(dst + ((rot + 2) & 3) * CP) = w2; *reinterpret_cast<uint2*>(dst + ((rot + 3) & 3) * CP) = w3;
+          }
         }
       }
     }

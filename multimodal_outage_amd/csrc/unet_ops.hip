@@ -210,6 +210,9 @@ static void ub_launch(const UbConvArgs& A, int Co, bool two, dim3 grid, hipStrea
       return;
     }
   }
+  if constexpr (CP == 16 && TW == UB_TW) {                // fp32 first view (the 13-channel network input): conflict-free staging order
+    if (Co <= 16 && !A.c.bf0) { hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 1, RB, false, TW, 1, true>), grid, dim3(256), 0, st, A); return; }
+  }
   if (Co <= 16) hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 1, RB, false, TW>), grid, dim3(256), 0, st, A);
   else hipLaunchKernelGGL((ub_conv3x3_kernel<CP, 2, RB, false, TW>), grid, dim3(256), 0, st, A);
 }
