@@ -416,7 +416,8 @@ int mo_raster_prepare(const float* raw, long n, int h, int w, float fill_value, 
 /* A/B switches of the UNet kernels for measurements (defaults are the product path):
  *   "no_mfma_wgrad" 1: the VALU / split-K 3x3 weight gradients;  "no_mfma_conv" 1: deep-level convs on the tile engine;
  *   "no_bf16_mfma" 1: MO_BF_MATH requests on the fp32 kernels;   "ub_min_w" 32: the 32 x 32 level on the bf16 conv too;
- *   "ux_min_co": smallest output-channel count on the fp32 matrix-pipe conv;
+ *   "ux_min_co": smallest output-channel count on the fp32 matrix-pipe conv at >= 32 x 32 pixels (16);
+ *   "ux_split" n: workgroups per tile of that conv, each with its share of the 16-channel output blocks (0: heuristic);
  *   "ub_no_pack" 1: thin outputs (Co <= 8) on the unpacked D[pixel][co] kernel;  "ub_ipw" n: images per workgroup;
  *   "fc_wide" 0: one 16-column block of W per wave in the 3 x bf16 FC kernels;  "fc_groups_grid" 1: FC row groups in
  *   the grid instead of inside the workgroup.

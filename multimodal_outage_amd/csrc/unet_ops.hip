@@ -31,7 +31,9 @@ static int mo_opt_fc_groups_grid = 0;     // FC row groups of 144: 1 = in the gr
 static int mo_opt_fc_wide = 1;            // FC kernels: 1 = two 16-column blocks per wave, 64-element chunks; 0 = first version (A/B)
 static int mo_opt_ub_no_pack = 0;         // A/B switch: 1 = thin outputs on the unpacked D[pixel][co] kernel
 static int mo_opt_ub_ipw = 0;             // experiment: images per workgroup of the bf16 conv (0 = heuristic)
-static int mo_opt_ux_min_co = 17;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
+static int mo_opt_ux_min_co = 16;        // smallest output-channel count routed to the matrix-pipe conv at >= 32x32 pixels
+                                         // (17 until the k-step offsets were formed once per kernel: 32 -> 16 at 32^2 61 -> 28 us,
+                                         //  the fp32 mode's 16-channel layers at 64^2 74 -> 50 / 63 -> 44 us)
 static int mo_opt_ux_split = 0;          // workgroups per tile of the fp32 matrix-pipe conv (output channels dealt out): 0 = heuristic
 extern "C" int mo_unet_set_option(const char* name, int value) {
   if (!name) return MO_EINVAL;
