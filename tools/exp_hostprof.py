@@ -39,3 +39,29 @@ L.call = spy
 import multimodal_outage_amd.unet_engine as ue, multimodal_outage_amd.gwnet_engine as ge
 step(); torch.cuda.synchronize(); L.call = orig
 print('C-ABI launches per step:', sum(calls.values()), sorted(calls.items(), key=lambda kv: -kv[1])[:12])
+# (b) cProfile of the two Functions' backward (they run on the autograd engine's thread: the profiler is switched on inside them)
+pr = cProfile.Profile()
+for Fn in (ue.UnetDecodeFn, ue.UnetEncodeFn):
+    ob = Fn.backward
+    def wrap(ctx, *g, _o=ob):
+        pr.enable()
+        try:
+            return _o(ctx, *g)
+        finally:
+            pr.disable()
+    Fn.backward = staticmethod(wrap)
+for _ in range(10):
+    step()
+torch.cuda.synchronize()
+sio = io.StringIO()
+pstats.Stats(pr, stream=sio).sort_stats('tottime').print_stats(28)
+print(sio.getvalue()[:6000])
+pf = cProfile.Profile()
+pf.enable()
+for _ in range(10):
+    out = m(x, td)
+pf.disable()
+torch.cuda.synchronize()
+sio = io.StringIO()
+pstats.Stats(pf, stream=sio).sort_stats('tottime').print_stats(18)
+print(sio.getvalue()[:4000])
