@@ -303,8 +303,14 @@ __global__ __launch_bounds__(256, 2) void ub_conv3x3_kernel(UbConvArgs A) {
             const char* ap = lds + (abase[m] + rr * (LDT * CP * 2)) + tb * 16 * DX * CP * 2;
             ub_bf8 pf;
             if (CP == 4) {                                  // 8-byte aligned only
+              // TWO ds_read_b64, not one ds_read2_b64 (the second offset is hidden from the compiler): the lanes of a pixel
+              // group row are 32 bytes apart -- over the 32 banks of a ds_read2_b64 a 4-way conflict on either half
+              // (conflict / active cycles 5.6, a quarter of the kernel's instruction waits), over the 64 banks of a
+              // ds_read_b64 2-way
+              int o2 = abase[m] + rr * (LDT * CP * 2) + tb * 16 * DX * CP * 2 + 8;
+              asm volatile("" : "+v"(o2));
               const uint2 lo = *reinterpret_cast<const uint2*>(ap);
-              const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
+              const uint2 hi = *reinterpret_cast<const uint2*>(lds + o2);
               pf = __builtin_bit_cast(ub_bf8, make_uint4(lo.x, lo.y, hi.x, hi.y));
             } else {
               pf = __builtin_bit_cast(ub_bf8, *reinterpret_cast<const uint4*>(ap));
