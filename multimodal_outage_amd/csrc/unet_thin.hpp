@@ -364,6 +364,9 @@ struct UtLossArgs {
 // first use -- with the loads inside `if (co < Co)` blocks the first version kept 13 dependent load -> use chains per
 // piece and ran at 1.05 TB/s.  Channels past Co re-read the last real plane (a cache hit) and are masked out; the
 // weights are wave-uniform scalar loads.
+// (The absolute-percentage term multiplies by v_rcp_f32 -- 1 ulp -- instead of dividing: the IEEE division sequence was 52
+//  x ~11 of the forward pass's ~1460 VALU instructions per 272-byte piece, in a kernel whose counters say VALU, not HBM:
+//  12.5 k VALU per wave against 145 loads.  MAPE is a logged mean of ~1e8 such terms; the tests hold it to 1e-4.)
 template <int CO, int MODE>
 __global__ __launch_bounds__(256, 2) void ut_outc_loss_kernel(UtLossArgs a) {
   constexpr int CI = 4, NS = MODE ? CO * CI + CO : 3;
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void ut_outc_loss_kernel(UtLossArgs a) {
           for (int ci = 0; ci < CI; ++ci) s += wsm[co][ci] * x[ci][k];
           o[k] = s;
           const float e = (s - tv[k]) * valid;
-          if (MODE == 0) { const float ae = fabsf(e); s_sq += e * e; s_abs += ae; s_ape += ae / fmaxf(fabsf(tv[k]), 1.17e-06f); }
+          if (MODE == 0) { const float ae = fabsf(e); s_sq += e * e; s_abs += ae; s_ape += ae * __builtin_amdgcn_rcpf(fmaxf(fabsf(tv[k]), 1.17e-06f)); }
           d[k] = e * a.inv_n2;
         }
         if (MODE == 0) {
