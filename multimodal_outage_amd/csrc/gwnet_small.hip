@@ -72,8 +72,8 @@ static inline long sg_slab_floats(int nsup) { return SG_S_WM + 32L * 32 * (1 + 2
 
 // sigmoid / tanh on the hardware exp and reciprocal, as the general engine's gate epilogues (mo_gemm.hpp mo_sigmoid /
 // mo_tanh: ~1e-6 relative; the libm tanhf is an order of magnitude more VALU instructions -- it was most of phase A)
-__device__ __forceinline__ float sg_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float sg_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+__device__ __forceinline__ float sg_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float sg_tanh(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 // One 16x16 output tile: acc += A_op[16][32 kc .. 32 kc + 31] * B_op[..][16] for kc in [0, kchunks); the loaders fill
 // a[j] = A_op[m0 + lane%16][32 kc + 8 q + j], b[j] = B_op[32 kc + 8 q + j][n0 + lane%16] (q = lane / 16): the MFMA's four

@@ -361,9 +361,12 @@ __device__ __forceinline__ void mo_fill_aff(float* aff, const MoOperand& op, int
 }
 
 // sigmoid / tanh on the hardware exp and reciprocal (v_exp_f32, v_rcp_f32): ~1e-6 relative error, and an
-// order of magnitude fewer VALU instructions than the libm tanhf, which made the gate epilogues VALU-bound
-__device__ __forceinline__ float mo_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float mo_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+// order of magnitude fewer VALU instructions than the libm tanhf, which made the gate epilogues VALU-bound.
+// (__builtin_amdgcn_rcpf IS v_rcp_f32, 1 ulp; __frcp_rn, used here until the end of round 3, is the correctly rounded
+//  reciprocal -- the whole IEEE division sequence, v_div_scale x2 + v_rcp + 4 fma + v_div_fmas + v_div_fixup: a third of
+//  the gated-TCN kernel's VALU instructions, in a kernel whose counters say VALU-bound.)
+__device__ __forceinline__ float mo_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float mo_tanh(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 template <int TM, int TN, int WM, int WN, int AMODE, int BMODE, int EPI>
 __device__ __forceinline__ void mo_epilogue(f32x16 (&acc)[TM][TN], const MoOperand& A, const MoOperand& B, const MoEpi& E,
